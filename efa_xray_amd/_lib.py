@@ -1,0 +1,383 @@
+"""ctypes binding of libefa_hip.so (C ABI declared in include/efa_hip.h).
+
+There is no CPU fallback anywhere in this package: if the shared library is
+missing, or no gfx950 device is usable, the calls below raise.
+"""
+import ctypes
+import os
+import sys
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libefa_hip.so")
+
+EFA_OK = 0
+EFA_ERR_INVALID = -1
+EFA_ERR_NO_DEVICE = -2
+EFA_ERR_HIP = -3
+EFA_ERR_UNSUPPORTED = -4
+
+LOC_NONE = 0
+LOC_GC = 1
+
+PATH_AUTO = 0
+PATH_SWEEP = 1
+PATH_TRANSFORM = 2
+
+c_double_p = ctypes.POINTER(ctypes.c_double)
+c_uint8_p = ctypes.POINTER(ctypes.c_uint8)
+c_int64_p = ctypes.POINTER(ctypes.c_int64)
+c_void_pp = ctypes.POINTER(ctypes.c_void_p)
+
+# every exported symbol with its (restype, argtypes); tests check this table
+# against include/efa_hip.h and against the built library.
+SIGNATURES = {
+    "efa_abi_version": (ctypes.c_int, []),
+    "efa_last_error": (ctypes.c_char_p, []),
+    "efa_device_count": (ctypes.c_int, [ctypes.POINTER(ctypes.c_int)]),
+    "efa_ctx_create": (ctypes.c_int, [ctypes.c_int, c_void_pp]),
+    "efa_ctx_destroy": (ctypes.c_int, [ctypes.c_void_p]),
+    "efa_ctx_set_stream": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p]),
+    "efa_ctx_set_option": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_char_p, ctypes.c_long]),
+    "efa_ctx_get_option": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_char_p, ctypes.POINTER(ctypes.c_long)]),
+    "efa_ctx_synchronize": (ctypes.c_int, [ctypes.c_void_p]),
+    "efa_malloc": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_size_t, c_void_pp]),
+    "efa_free": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p]),
+    "efa_memcpy_h2d": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t]),
+    "efa_memcpy_d2h": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t]),
+    "efa_memcpy_d2d": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t]),
+    "efa_form_perts_dev": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_long, ctypes.c_int, ctypes.c_void_p,
+                                          ctypes.c_double, ctypes.c_void_p, ctypes.c_void_p]),
+    "efa_posterior_dev": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_long, ctypes.c_int, ctypes.c_void_p,
+                                         ctypes.c_void_p, ctypes.c_void_p]),
+    "efa_forward_stencil_dev": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_long, ctypes.c_long, ctypes.c_int,
+                                               ctypes.c_void_p, ctypes.c_long, ctypes.c_int, c_int64_p,
+                                               c_double_p, ctypes.c_void_p]),
+    "efa_ensrf_update_dev": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_long, ctypes.c_int, ctypes.c_long,
+                                            ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p,
+                                            c_double_p, c_double_p, c_uint8_p, ctypes.c_int,
+                                            c_double_p, c_double_p, c_double_p, c_double_p, c_double_p,
+                                            ctypes.c_long, ctypes.c_long,
+                                            c_double_p, c_double_p, c_double_p, c_double_p, c_uint8_p]),
+    "efa_obs_phase_dev": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, ctypes.c_long, ctypes.c_void_p,
+                                         ctypes.c_void_p, c_double_p, c_double_p, c_uint8_p, ctypes.c_int,
+                                         c_double_p, c_double_p, c_double_p,
+                                         c_double_p, c_double_p, c_double_p, c_double_p, c_uint8_p]),
+    "efa_state_phase_dev": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_long, ctypes.c_int, ctypes.c_void_p,
+                                           ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p,
+                                           c_double_p, c_double_p, ctypes.c_long, ctypes.c_long]),
+    "efa_state_cycle_dev": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_long, ctypes.c_int, ctypes.c_void_p,
+                                           ctypes.c_void_p, c_double_p, c_double_p, ctypes.c_long,
+                                           ctypes.c_long]),
+    "efa_ensrf_update": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_long, ctypes.c_long, ctypes.c_int,
+                                        ctypes.c_long, c_double_p, c_double_p,
+                                        c_double_p, c_double_p, c_uint8_p, ctypes.c_int,
+                                        c_double_p, c_double_p, c_double_p, c_double_p, c_double_p,
+                                        ctypes.c_long, ctypes.c_long,
+                                        c_double_p, c_double_p, c_double_p, c_double_p, c_uint8_p]),
+    "efa_last_timing": (ctypes.c_int, [ctypes.c_void_p, c_double_p, c_double_p,
+                                       ctypes.POINTER(ctypes.c_long), ctypes.POINTER(ctypes.c_int)]),
+    "efa_fill_synthetic_dev": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_long, ctypes.c_long, ctypes.c_int,
+                                              ctypes.c_uint64, ctypes.c_double, ctypes.c_void_p]),
+}
+
+
+class EfaError(RuntimeError):
+    """A libefa_hip call failed (status < 0); message from efa_last_error()."""
+
+    def __init__(self, status, message):
+        RuntimeError.__init__(self, "libefa_hip error %d: %s" % (status, message))
+        self.status = status
+
+
+_lib = None
+
+
+def load_library(path=None):
+    """dlopen libefa_hip.so (once) and declare every prototype.
+
+    Raises RuntimeError if the library has not been built -- build it with
+    `python -c "import __graft_entry__ as g; g.build()"` or
+    `make -C efa_xray_amd/csrc`.  Nothing falls back to a CPU path.
+    """
+    global _lib
+    if _lib is not None and path is None:
+        return _lib
+    p = path or LIB_PATH
+    if not os.path.exists(p):
+        raise RuntimeError(
+            "libefa_hip.so not found at %s: the HIP extension is not built "
+            "(run `make -C %s`); efa_xray_amd has no CPU fallback" % (p, os.path.join(_HERE, "csrc")))
+    lib = ctypes.CDLL(p)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)          # AttributeError if a symbol is missing
+        fn.restype = res
+        fn.argtypes = args
+    if lib.efa_abi_version() != 1:
+        raise RuntimeError("libefa_hip ABI version %d, expected 1" % lib.efa_abi_version())
+    if path is None:
+        _lib = lib
+    return lib
+
+
+def _check(lib, status):
+    if status != EFA_OK:
+        msg = lib.efa_last_error()
+        raise EfaError(status, msg.decode("utf-8", "replace") if msg else "")
+
+
+def device_count():
+    lib = load_library()
+    n = ctypes.c_int(0)
+    _check(lib, lib.efa_device_count(ctypes.byref(n)))
+    return n.value
+
+
+def _dp(a):
+    """double* view of a C-contiguous float64 ndarray (or NULL)."""
+    if a is None:
+        return None
+    assert a.dtype == np.float64 and a.flags["C_CONTIGUOUS"]
+    return a.ctypes.data_as(c_double_p)
+
+
+def _u8p(a):
+    if a is None:
+        return None
+    assert a.dtype == np.uint8 and a.flags["C_CONTIGUOUS"]
+    return a.ctypes.data_as(c_uint8_p)
+
+
+class DeviceArray(object):
+    """A float64 array in the context GPU's HBM (hipMalloc via efa_malloc)."""
+
+    def __init__(self, ctx, shape):
+        self.ctx = ctx
+        self.shape = tuple(int(s) for s in np.atleast_1d(shape))
+        self.nbytes = int(np.prod(self.shape, dtype=np.int64)) * 8
+        ptr = ctypes.c_void_p()
+        _check(ctx.lib, ctx.lib.efa_malloc(ctx.handle, self.nbytes, ctypes.byref(ptr)))
+        self.ptr = ptr
+
+    @property
+    def address(self):
+        return self.ptr.value
+
+    def upload(self, host):
+        host = np.ascontiguousarray(host, dtype=np.float64)
+        assert host.nbytes == self.nbytes, (host.shape, self.shape)
+        _check(self.ctx.lib, self.ctx.lib.efa_memcpy_h2d(self.ctx.handle, self.ptr, host.ctypes.data, self.nbytes))
+        return self
+
+    def download(self, out=None):
+        if out is None:
+            out = np.empty(self.shape, dtype=np.float64)
+        assert out.nbytes == self.nbytes and out.flags["C_CONTIGUOUS"]
+        _check(self.ctx.lib, self.ctx.lib.efa_memcpy_d2h(self.ctx.handle, out.ctypes.data, self.ptr, self.nbytes))
+        return out
+
+    def free(self):
+        if self.ptr is not None and self.ptr.value and self.ctx.handle is not None:
+            self.ctx.lib.efa_free(self.ctx.handle, self.ptr)
+        self.ptr = None
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
+
+
+class Context(object):
+    """One efa_ctx: a GPU, its stream and its workspaces."""
+
+    def __init__(self, device=0):
+        self.lib = load_library()
+        self.handle = None
+        h = ctypes.c_void_p()
+        _check(self.lib, self.lib.efa_ctx_create(int(device), ctypes.byref(h)))
+        self.handle = h
+        self.device = int(device)
+
+    def close(self):
+        if self.handle is not None:
+            self.lib.efa_ctx_destroy(self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # -- options ------------------------------------------------------------
+    def set_option(self, key, value):
+        _check(self.lib, self.lib.efa_ctx_set_option(self.handle, key.encode(), int(value)))
+
+    def get_option(self, key):
+        v = ctypes.c_long(0)
+        _check(self.lib, self.lib.efa_ctx_get_option(self.handle, key.encode(), ctypes.byref(v)))
+        return v.value
+
+    def set_stream(self, hip_stream):
+        _check(self.lib, self.lib.efa_ctx_set_stream(self.handle, ctypes.c_void_p(hip_stream or 0)))
+
+    def synchronize(self):
+        _check(self.lib, self.lib.efa_ctx_synchronize(self.handle))
+
+    # -- memory ---------------------------------------------------------------
+    def empty(self, shape):
+        return DeviceArray(self, shape)
+
+    def to_device(self, host):
+        host = np.ascontiguousarray(host, dtype=np.float64)
+        return DeviceArray(self, host.shape).upload(host)
+
+    # -- kernels --------------------------------------------------------------
+    @staticmethod
+    def _addr(x):
+        if x is None:
+            return None
+        if isinstance(x, DeviceArray):
+            return x.ptr
+        return ctypes.c_void_p(int(x))      # raw device address (e.g. torch data_ptr())
+
+    def form_perts(self, rows, M, X, xm, Xp, scale=1.0):
+        _check(self.lib, self.lib.efa_form_perts_dev(self.handle, rows, M, self._addr(X), float(scale),
+                                                     self._addr(xm), self._addr(Xp)))
+
+    def posterior(self, rows, M, xm, Xp, post):
+        _check(self.lib, self.lib.efa_posterior_dev(self.handle, rows, M, self._addr(xm), self._addr(Xp),
+                                                    self._addr(post)))
+
+    def forward_stencil(self, rows, row_offset, M, X, idx, wts, HX):
+        idx = np.ascontiguousarray(idx, dtype=np.int64)
+        wts = np.ascontiguousarray(wts, dtype=np.float64)
+        assert idx.ndim == 2 and idx.shape == wts.shape
+        P, npt = idx.shape
+        _check(self.lib, self.lib.efa_forward_stencil_dev(
+            self.handle, rows, row_offset, M, self._addr(X), P, npt,
+            idx.ctypes.data_as(c_int64_p), _dp(wts), self._addr(HX)))
+
+    @staticmethod
+    def _ob_arrays(P, ob_value, ob_error, ob_assim, loc_mode, ob_lat, ob_lon, ob_halfwidth):
+        val = np.ascontiguousarray(ob_value, dtype=np.float64).reshape(P)
+        err = np.ascontiguousarray(ob_error, dtype=np.float64).reshape(P)
+        asm = np.ascontiguousarray(np.asarray(ob_assim).astype(bool), dtype=np.uint8).reshape(P)
+        lat = lon = hw = None
+        if loc_mode == LOC_GC:
+            lat = np.ascontiguousarray(ob_lat, dtype=np.float64).reshape(P)
+            lon = np.ascontiguousarray(ob_lon, dtype=np.float64).reshape(P)
+            hw = np.ascontiguousarray(ob_halfwidth, dtype=np.float64).reshape(P)
+        return val, err, asm, lat, lon, hw
+
+    @staticmethod
+    def _diag_arrays(P):
+        return dict(prior_mean=np.full(P, np.nan), prior_var=np.full(P, np.nan),
+                    post_mean=np.full(P, np.nan), post_var=np.full(P, np.nan),
+                    assimilated=np.zeros(P, dtype=np.uint8))
+
+    @staticmethod
+    def _grid(loc_mode, grid_lat, grid_lon):
+        if loc_mode != LOC_GC:
+            return None, None, 0
+        glat = np.ascontiguousarray(grid_lat, dtype=np.float64).reshape(-1)
+        glon = np.ascontiguousarray(grid_lon, dtype=np.float64).reshape(-1)
+        assert glat.shape == glon.shape
+        return glat, glon, glat.shape[0]
+
+    def obs_phase(self, M, P, ym, Yp, ob_value, ob_error, ob_assim, loc_mode=LOC_NONE,
+                  ob_lat=None, ob_lon=None, ob_halfwidth=None):
+        """Phase A.  Returns the per-ob diagnostics dict."""
+        val, err, asm, lat, lon, hw = self._ob_arrays(P, ob_value, ob_error, ob_assim, loc_mode,
+                                                      ob_lat, ob_lon, ob_halfwidth)
+        d = self._diag_arrays(P)
+        _check(self.lib, self.lib.efa_obs_phase_dev(
+            self.handle, M, P, self._addr(ym), self._addr(Yp), _dp(val), _dp(err), _u8p(asm), loc_mode,
+            _dp(lat), _dp(lon), _dp(hw), _dp(d["prior_mean"]), _dp(d["prior_var"]), _dp(d["post_mean"]),
+            _dp(d["post_var"]), _u8p(d["assimilated"])))
+        d["assimilated"] = d["assimilated"].astype(bool)
+        return d
+
+    def state_phase(self, rows, M, xm_in, Xp_in, xm_out, Xp_out, grid_lat=None, grid_lon=None, n_lead=1):
+        loc_mode = LOC_GC if grid_lat is not None else LOC_NONE
+        glat, glon, ncol = self._grid(loc_mode, grid_lat, grid_lon)
+        if loc_mode == LOC_NONE:
+            ncol, n_lead = rows, 1
+        _check(self.lib, self.lib.efa_state_phase_dev(
+            self.handle, rows, M, self._addr(xm_in), self._addr(Xp_in), self._addr(xm_out),
+            self._addr(Xp_out), _dp(glat), _dp(glon), ncol, n_lead))
+
+    def state_cycle(self, rows, M, X, post, grid_lat=None, grid_lon=None, n_lead=1):
+        loc_mode = LOC_GC if grid_lat is not None else LOC_NONE
+        glat, glon, ncol = self._grid(loc_mode, grid_lat, grid_lon)
+        if loc_mode == LOC_NONE:
+            ncol, n_lead = rows, 1
+        _check(self.lib, self.lib.efa_state_cycle_dev(
+            self.handle, rows, M, self._addr(X), self._addr(post), _dp(glat), _dp(glon), ncol, n_lead))
+
+    def ensrf_update_dev(self, rows, M, P, xm, Xp, ym, Yp, ob_value, ob_error, ob_assim,
+                         loc_mode=LOC_NONE, ob_lat=None, ob_lon=None, ob_halfwidth=None,
+                         grid_lat=None, grid_lon=None, n_lead=1):
+        val, err, asm, lat, lon, hw = self._ob_arrays(P, ob_value, ob_error, ob_assim, loc_mode,
+                                                      ob_lat, ob_lon, ob_halfwidth)
+        glat, glon, ncol = self._grid(loc_mode, grid_lat, grid_lon)
+        if loc_mode == LOC_NONE:
+            ncol, n_lead = rows, 1
+        d = self._diag_arrays(P)
+        _check(self.lib, self.lib.efa_ensrf_update_dev(
+            self.handle, rows, M, P, self._addr(xm), self._addr(Xp), self._addr(ym), self._addr(Yp),
+            _dp(val), _dp(err), _u8p(asm), loc_mode, _dp(lat), _dp(lon), _dp(hw), _dp(glat), _dp(glon),
+            ncol, n_lead, _dp(d["prior_mean"]), _dp(d["prior_var"]), _dp(d["post_mean"]),
+            _dp(d["post_var"]), _u8p(d["assimilated"])))
+        d["assimilated"] = d["assimilated"].astype(bool)
+        return d
+
+    def ensrf_update_host(self, xbm, Xbp, nstate, ob_value, ob_error, ob_assim, loc_mode=LOC_NONE,
+                          ob_lat=None, ob_lon=None, ob_halfwidth=None, grid_lat=None, grid_lon=None,
+                          n_lead=1):
+        """efa_ensrf_update on the reference's augmented host arrays, in place."""
+        assert xbm.dtype == np.float64 and Xbp.dtype == np.float64
+        assert xbm.flags["C_CONTIGUOUS"] and Xbp.flags["C_CONTIGUOUS"]
+        A, M = Xbp.shape
+        P = A - nstate
+        val, err, asm, lat, lon, hw = self._ob_arrays(P, ob_value, ob_error, ob_assim, loc_mode,
+                                                      ob_lat, ob_lon, ob_halfwidth)
+        glat, glon, ncol = self._grid(loc_mode, grid_lat, grid_lon)
+        if loc_mode == LOC_NONE:
+            ncol, n_lead = nstate, 1
+        d = self._diag_arrays(P)
+        _check(self.lib, self.lib.efa_ensrf_update(
+            self.handle, A, nstate, M, P, _dp(xbm), _dp(Xbp), _dp(val), _dp(err), _u8p(asm), loc_mode,
+            _dp(lat), _dp(lon), _dp(hw), _dp(glat), _dp(glon), ncol, n_lead,
+            _dp(d["prior_mean"]), _dp(d["prior_var"]), _dp(d["post_mean"]), _dp(d["post_var"]),
+            _u8p(d["assimilated"])))
+        d["assimilated"] = d["assimilated"].astype(bool)
+        return d
+
+    def last_timing(self):
+        s = ctypes.c_double(0)
+        o = ctypes.c_double(0)
+        n = ctypes.c_long(0)
+        p = ctypes.c_int(0)
+        _check(self.lib, self.lib.efa_last_timing(self.handle, ctypes.byref(s), ctypes.byref(o),
+                                                  ctypes.byref(n), ctypes.byref(p)))
+        return dict(state_ms=s.value, obs_ms=o.value, state_launches=n.value, path=p.value)
+
+    def fill_synthetic(self, rows, row_offset, M, seed, sigma, X):
+        _check(self.lib, self.lib.efa_fill_synthetic_dev(self.handle, rows, row_offset, M, int(seed),
+                                                         float(sigma), self._addr(X)))
+
+
+_contexts = {}
+
+
+def get_context(device=0):
+    """Process-wide cached context per device."""
+    device = int(device)
+    ctx = _contexts.get(device)
+    if ctx is None or ctx.handle is None:
+        ctx = Context(device)
+        _contexts[device] = ctx
+    return ctx

@@ -1,0 +1,169 @@
+"""EnSRF: serial ensemble square-root filter, computed on an MI355X.
+
+Drop-in for the reference's `EnSRF(Assimilation)`
+(efa_xray/assimilation/ensrf.py:8-151): same constructor
+`EnSRF(state, obs, nproc=1, inflation=None, verbose=True, loc=False)`, same
+`.update() -> (post_state, obs)` with `post_state` a new object and the five
+diagnostics (`prior_mean, prior_var, post_mean, post_var, assimilated`,
+ensrf.py:66,70,75,146-149) written onto each `Observation` in place.
+
+The per-observation loop (ensrf.py:50-149) does not exist in Python here:
+`update()` marshals the state vector and the per-ob scalars into flat arrays
+and calls libefa_hip (`efa_obs_phase_dev` + `efa_state_cycle_dev`).  If the
+library or a gfx950 GPU is missing the call raises -- there is no NumPy path.
+"""
+from copy import deepcopy
+
+import numpy as np
+
+from efa_xray_amd import _lib
+from efa_xray_amd.assimilation.assimilation import Assimilation
+
+
+class EnSRF(Assimilation):
+    def __init__(self, state, obs, nproc=1, inflation=None, verbose=True, loc=False, **kw):
+        """Extra keyword-only options (all default to reference behaviour):
+        device   -- HIP device ordinal (default 0)
+        obs_batch-- observations fused per sweep launch (1..64)
+        path     -- 'auto' | 'sweep' | 'transform' (how the state sweep runs)
+        """
+        device = kw.pop("device", 0)
+        self.obs_batch = kw.pop("obs_batch", None)
+        self.path = kw.pop("path", None)
+        if kw:
+            raise TypeError("unexpected keyword arguments %r" % sorted(kw))
+        Assimilation.__init__(self, state, obs, nproc, inflation, verbose, device=device)
+        self.loc = loc
+        self.last_timing = None
+
+    # ------------------------------------------------------------------
+    def _loc_mode(self):
+        if self.loc in (None, False):
+            return _lib.LOC_NONE
+        if self.loc == 'GC':
+            return _lib.LOC_GC
+        # ensrf.py:99-101 passes any other truthy value to Observation.localize,
+        # which then hits an unbound local (observation.py:77-87)
+        raise ValueError("loc=%r: supported values are None, False and 'GC'" % (self.loc,))
+
+    def _ob_arrays(self, loc_mode):
+        obs = self.obs
+        P = len(obs)
+        value = np.array([float(ob.value) if ob.assimilate_this else
+                          (np.nan if ob.value is None else float(ob.value)) for ob in obs], dtype=np.float64)
+        error = np.array([float(ob.error) if ob.assimilate_this else
+                          (np.nan if ob.error is None else float(ob.error)) for ob in obs], dtype=np.float64)
+        assim = np.array([bool(ob.assimilate_this) for ob in obs], dtype=bool)
+        lat = lon = hw = None
+        if loc_mode == _lib.LOC_GC:
+            for k, ob in enumerate(obs):
+                if ob.localize_radius is None:
+                    raise ValueError("observation %d has localize_radius=None but loc='GC' "
+                                     "(the reference raises TypeError in abs(None), observation.py:120)" % k)
+            lat = np.array([float(ob.lat) for ob in obs], dtype=np.float64)
+            lon = np.array([float(ob.lon) for ob in obs], dtype=np.float64)
+            hw = np.array([float(ob.localize_radius) for ob in obs], dtype=np.float64)
+        return P, value, error, assim, lat, lon, hw
+
+    def _configure(self, ctx):
+        if self.obs_batch is not None:
+            ctx.set_option("obs_batch", int(self.obs_batch))
+        path = {None: _lib.PATH_AUTO, "auto": _lib.PATH_AUTO, "sweep": _lib.PATH_SWEEP,
+                "transform": _lib.PATH_TRANSFORM}[self.path]
+        ctx.set_option("path", path)
+
+    # ------------------------------------------------------------------
+    def update(self):
+        if self.verbose:
+            print("Beginning update sequence")
+        prior = self.prior
+        N = prior.nstate()
+        M = prior.nmems()
+        loc_mode = self._loc_mode()
+        P, value, error, assim, lat, lon, hw = self._ob_arrays(loc_mode)
+        scale = self._inflation_factor() if self.inflation is not None else 1.0
+        if self.inflation is not None:
+            self.inflate_state()
+
+        # forward operator, once per ob from the prior (assimilation.py:45-48)
+        if self.verbose:
+            print("Computing observation priors")
+        HX = self.compute_ob_estimates()
+
+        ctx = self._context()
+        self._configure(ctx)
+        ctx.set_option("timing", 1)
+        if self.verbose:
+            print("Converting state to vector")
+        X = ctx.to_device(np.ascontiguousarray(prior.to_vect(), dtype=np.float64))
+        ym = ctx.empty((max(P, 1),))
+        Yp = ctx.to_device(HX) if P else ctx.empty((1, M))
+        if P:
+            ctx.form_perts(P, M, Yp, ym, Yp, scale=scale)      # assimilation.py:46-48
+
+        grid_lat = grid_lon = None
+        n_lead = 1
+        if loc_mode == _lib.LOC_GC:
+            grid_lat, grid_lon = prior.column_latlon()          # 2-D taper, ensrf.py:108-111
+            n_lead = prior.nvars() * prior.ntimes()
+
+        if self.verbose:
+            print("Beginning observation loop")
+        diag = ctx.obs_phase(M, P, ym, Yp, value, error, assim, loc_mode, lat, lon, hw)
+        if scale == 1.0:
+            ctx.state_cycle(N, M, X, X, grid_lat, grid_lon, n_lead)
+        else:
+            xm = ctx.empty((N,))
+            ctx.form_perts(N, M, X, xm, X, scale=scale)
+            ctx.state_phase(N, M, xm, X, xm, X, grid_lat, grid_lon, n_lead)
+            ctx.posterior(N, M, xm, X, X)
+        self.last_timing = ctx.last_timing()
+        post = X.download()
+
+        # diagnostics onto the observations, as ensrf.py:66,70,75,146-149
+        for k, ob in enumerate(self.obs):
+            ob.prior_mean = np.float64(diag["prior_mean"][k])
+            ob.prior_var = np.float64(diag["prior_var"][k])
+            if diag["assimilated"][k]:
+                ob.post_mean = np.float64(diag["post_mean"][k])
+                ob.post_var = np.float64(diag["post_var"][k])
+                ob.assimilated = True
+            else:
+                ob.assimilated = False
+
+        if self.verbose:
+            print("Formatting posterior")
+        post_state = deepcopy(self.prior)                       # assimilation.py:165
+        post_state.from_vect(post)
+        return post_state, self.obs
+
+    # ------------------------------------------------------------------
+    def update_arrays(self, xbm, Xbp):
+        """Run the loop on the reference's augmented arrays (as returned by
+        `format_prior_state`) and return `(xam, Xap)` as handed to
+        `format_posterior_state` (ensrf.py:44,151).  Diagnostics are written
+        onto the observations."""
+        loc_mode = self._loc_mode()
+        P, value, error, assim, lat, lon, hw = self._ob_arrays(loc_mode)
+        N = self.prior.nstate()
+        xam = np.array(xbm, dtype=np.float64, order="C")
+        Xap = np.array(Xbp, dtype=np.float64, order="C")
+        grid_lat = grid_lon = None
+        n_lead = 1
+        if loc_mode == _lib.LOC_GC:
+            grid_lat, grid_lon = self.prior.column_latlon()
+            n_lead = self.prior.nvars() * self.prior.ntimes()
+        ctx = self._context()
+        self._configure(ctx)
+        diag = ctx.ensrf_update_host(xam, Xap, N, value, error, assim, loc_mode, lat, lon, hw,
+                                     grid_lat, grid_lon, n_lead)
+        for k, ob in enumerate(self.obs):
+            ob.prior_mean = np.float64(diag["prior_mean"][k])
+            ob.prior_var = np.float64(diag["prior_var"][k])
+            if diag["assimilated"][k]:
+                ob.post_mean = np.float64(diag["post_mean"][k])
+                ob.post_var = np.float64(diag["post_var"][k])
+                ob.assimilated = True
+            else:
+                ob.assimilated = False
+        return xam, Xap

@@ -1,0 +1,714 @@
+// C-ABI layer of libefa_hip.so (see include/efa_hip.h): contexts, workspaces,
+// the Phase A / Phase B drivers and the host-memory convenience entry point.
+#include "../../include/efa_hip.h"
+
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "efa_internal.h"
+
+namespace {
+
+thread_local std::string g_last_error;
+
+int fail(int code, const char* fmt, ...) {
+  char buf[512];
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(buf, sizeof(buf), fmt, ap);
+  va_end(ap);
+  g_last_error = buf;
+  return code;
+}
+
+#define EFA_HIP(expr)                                                                       \
+  do {                                                                                      \
+    hipError_t _e = (expr);                                                                 \
+    if (_e != hipSuccess)                                                                   \
+      return fail(EFA_ERR_HIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e), __FILE__, \
+                  __LINE__);                                                                \
+  } while (0)
+
+#define EFA_TRY(expr)          \
+  do {                         \
+    int _s = (expr);           \
+    if (_s != EFA_OK) return _s; \
+  } while (0)
+
+// grow-only device buffer
+struct DevBuf {
+  void* p = nullptr;
+  size_t cap = 0;
+  int reserve(size_t bytes) {
+    if (bytes <= cap) return EFA_OK;
+    if (p) {
+      hipError_t e = hipFree(p);
+      p = nullptr;
+      cap = 0;
+      if (e != hipSuccess) return fail(EFA_ERR_HIP, "hipFree failed: %s", hipGetErrorString(e));
+    }
+    size_t want = bytes + (bytes >> 3) + 256;
+    hipError_t e = hipMalloc(&p, want);
+    if (e != hipSuccess) {
+      p = nullptr;
+      return fail(EFA_ERR_HIP, "hipMalloc(%zu) failed: %s", want, hipGetErrorString(e));
+    }
+    cap = want;
+    return EFA_OK;
+  }
+  void release() {
+    if (p) (void)hipFree(p);
+    p = nullptr;
+    cap = 0;
+  }
+  template <typename T>
+  T* as() const { return reinterpret_cast<T*>(p); }
+};
+
+}  // namespace
+
+struct efa_ctx {
+  int device = 0;
+  hipStream_t own_stream = nullptr;
+  hipStream_t stream = nullptr;
+  long obs_batch = 32;
+  long path = EFA_PATH_AUTO;
+  long timing = 0;
+
+  // --- trajectory recorded by the last obs phase --------------------------
+  bool have_traj = false;
+  int M = 0;
+  long P = 0;
+  int loc_mode = EFA_LOC_NONE;
+  long n_active = 0;
+  bool have_transform = false;   // identity rows were carried: (T, w) valid
+  std::vector<uint8_t> h_assim;  // host copy of ob_assim
+  DevBuf Ye_rec, coef;           // [P][M], [P][4]
+  DevBuf ob_val, ob_err, ob_asm, ob_lat, ob_lon, ob_hw;  // device copies [P]
+  DevBuf d_prior_mean, d_prior_var, d_post_mean, d_post_var, d_assimilated;
+  DevBuf Yw, ymw;  // obs block workspace [(P+M)][M], [(P+M)]
+  // --- state phase workspaces ---------------------------------------------
+  DevBuf W;           // taper table [nb][ncol]
+  DevBuf glat, glon;  // grid lat/lon [ncol]
+  DevBuf xm_ws;       // means for efa_state_cycle_dev
+  // --- host-memory API buffers ----------------------------------------------
+  DevBuf h_xm, h_Xp, h_ym, h_Yp;
+  // --- timing -----------------------------------------------------------------
+  hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
+  double state_ms = 0.0, obs_ms = 0.0;
+  long state_launches = 0;
+  int path_taken = 0;
+  std::vector<double> h_tmp;
+  std::vector<uint8_t> h_tmp8;
+};
+
+namespace {
+
+using namespace efa;
+
+int use(efa_ctx* c) {
+  if (!c) return fail(EFA_ERR_INVALID, "null context");
+  EFA_HIP(hipSetDevice(c->device));
+  return EFA_OK;
+}
+
+long effective_batch(const efa_ctx* c, int M) {
+  long b = c->obs_batch;
+  if (b < 1) b = 1;
+  if (b > kMaxBatch) b = kMaxBatch;
+  // keep the sweep's LDS image of the batch (ye rows + coefs) under 60 KiB
+  int nch = (M + 7) / 8;
+  if (nch > 16) nch = (nch <= 20) ? 20 : (nch <= 24) ? 24 : 32;
+  const long per_ob = (long)(8 * nch + kCoefStride) * (long)sizeof(double);
+  const long cap = (60L * 1024) / per_ob;
+  if (b > cap) b = cap;
+  if (b < 1) b = 1;
+  return b;
+}
+
+int h2d(efa_ctx* c, DevBuf& b, const void* src, size_t bytes) {
+  EFA_TRY(b.reserve(bytes ? bytes : 8));
+  if (bytes) EFA_HIP(hipMemcpyAsync(b.p, src, bytes, hipMemcpyHostToDevice, c->stream));
+  return EFA_OK;
+}
+
+int check_common(int M, long P) {
+  if (M < 2) return fail(EFA_ERR_INVALID, "ensemble size M=%d must be >= 2 (covariance divides by M-1)", M);
+  if (M > kMaxMembers) return fail(EFA_ERR_UNSUPPORTED, "ensemble size M=%d exceeds the built maximum %d", M, kMaxMembers);
+  if (P < 0) return fail(EFA_ERR_INVALID, "negative observation count");
+  return EFA_OK;
+}
+
+// ---- Phase A ---------------------------------------------------------------
+int obs_phase(efa_ctx* c, int M, long P, double* ym_dev, double* Yp_dev, const double* ob_value,
+              const double* ob_error, const uint8_t* ob_assim, int loc_mode, const double* ob_lat,
+              const double* ob_lon, const double* ob_hw, double* prior_mean, double* prior_var,
+              double* post_mean, double* post_var, uint8_t* assimilated) {
+  EFA_TRY(check_common(M, P));
+  if (loc_mode != EFA_LOC_NONE && loc_mode != EFA_LOC_GC) return fail(EFA_ERR_INVALID, "loc_mode %d", loc_mode);
+  c->have_traj = false;
+  c->M = M;
+  c->P = P;
+  c->loc_mode = loc_mode;
+  c->n_active = 0;
+  c->have_transform = false;
+  c->obs_ms = 0.0;
+  if (P == 0) {
+    c->have_traj = true;
+    c->h_assim.clear();
+    return EFA_OK;
+  }
+  if (!ym_dev || !Yp_dev || !ob_value || !ob_error || !ob_assim)
+    return fail(EFA_ERR_INVALID, "null observation array");
+  if (loc_mode == EFA_LOC_GC) {
+    if (!ob_lat || !ob_lon || !ob_hw) return fail(EFA_ERR_INVALID, "GC localisation needs ob_lat/ob_lon/ob_halfwidth_km");
+    for (long k = 0; k < P; ++k)
+      if (!(ob_hw[k] == ob_hw[k]) || ob_hw[k] == 0.0)
+        return fail(EFA_ERR_INVALID, "observation %ld: localize_radius must be a non-zero number for loc='GC' "
+                    "(the reference raises in abs(None), observation.py:120)", k);
+  }
+  c->h_assim.assign(ob_assim, ob_assim + P);
+  for (long k = 0; k < P; ++k) c->n_active += ob_assim[k] ? 1 : 0;
+
+  const bool carry_T = (loc_mode == EFA_LOC_NONE) && transform_supported(M) && (c->path != EFA_PATH_SWEEP);
+  const long extra = carry_T ? M : 0;
+  const long R = P + extra;
+  const size_t dP = (size_t)P * sizeof(double);
+
+  EFA_TRY(h2d(c, c->ob_val, ob_value, dP));
+  EFA_TRY(h2d(c, c->ob_err, ob_error, dP));
+  EFA_TRY(h2d(c, c->ob_asm, ob_assim, (size_t)P));
+  if (loc_mode == EFA_LOC_GC) {
+    EFA_TRY(h2d(c, c->ob_lat, ob_lat, dP));
+    EFA_TRY(h2d(c, c->ob_lon, ob_lon, dP));
+    EFA_TRY(h2d(c, c->ob_hw, ob_hw, dP));
+  }
+  EFA_TRY(c->Ye_rec.reserve((size_t)P * M * sizeof(double)));
+  EFA_TRY(c->coef.reserve((size_t)P * kCoefStride * sizeof(double)));
+  EFA_TRY(c->d_prior_mean.reserve(dP));
+  EFA_TRY(c->d_prior_var.reserve(dP));
+  EFA_TRY(c->d_post_mean.reserve(dP));
+  EFA_TRY(c->d_post_var.reserve(dP));
+  EFA_TRY(c->d_assimilated.reserve((size_t)P));
+  EFA_TRY(c->Yw.reserve((size_t)R * M * sizeof(double)));
+  EFA_TRY(c->ymw.reserve((size_t)R * sizeof(double)));
+
+  hipStream_t s = c->stream;
+  if (c->timing) EFA_HIP(hipEventRecord(c->ev[0], s));
+  double* Yw = c->Yw.as<double>();
+  double* ymw = c->ymw.as<double>();
+  EFA_HIP(hipMemcpyAsync(Yw, Yp_dev, (size_t)P * M * sizeof(double), hipMemcpyDeviceToDevice, s));
+  EFA_HIP(hipMemcpyAsync(ymw, ym_dev, dP, hipMemcpyDeviceToDevice, s));
+  if (carry_T) EFA_HIP(launch_set_identity(M, Yw + (size_t)P * M, ymw + P, s));
+
+  const long B = effective_batch(c, M);
+  for (long b0 = 0; b0 < P; b0 += B) {
+    const int nb = (int)((P - b0 < B) ? (P - b0) : B);
+    DiagArgs d{};
+    d.Yp = Yw;
+    d.ym = ymw;
+    d.M = M;
+    d.b0 = b0;
+    d.nb = nb;
+    d.ob_value = c->ob_val.as<double>();
+    d.ob_error = c->ob_err.as<double>();
+    d.ob_assim = c->ob_asm.as<uint8_t>();
+    d.loc_mode = loc_mode;
+    d.ob_lat = c->ob_lat.as<double>();
+    d.ob_lon = c->ob_lon.as<double>();
+    d.ob_hw = c->ob_hw.as<double>();
+    d.Ye_rec = c->Ye_rec.as<double>();
+    d.coef = c->coef.as<double>();
+    d.prior_mean = c->d_prior_mean.as<double>();
+    d.prior_var = c->d_prior_var.as<double>();
+    d.post_mean = c->d_post_mean.as<double>();
+    d.post_var = c->d_post_var.as<double>();
+    d.assimilated = c->d_assimilated.as<uint8_t>();
+    EFA_HIP(launch_diag(d, s));
+
+    long act = 0;
+    for (int k = 0; k < nb; ++k) act += ob_assim[b0 + k] ? 1 : 0;
+    if (act == 0 || R == nb) continue;
+    SweepArgs a{};
+    a.Xin = Yw;
+    a.xin = ymw;
+    a.Xout = Yw;
+    a.xout = ymw;
+    a.nrows = R;
+    a.M = M;
+    a.Ye = c->Ye_rec.as<double>() + (size_t)b0 * M;
+    a.coef = c->coef.as<double>() + (size_t)b0 * kCoefStride;
+    a.nb = nb;
+    a.taper_mode = (loc_mode == EFA_LOC_GC) ? kTaperObs : kTaperNone;
+    a.row_lat = c->ob_lat.as<double>();
+    a.row_lon = c->ob_lon.as<double>();
+    a.ob_lat = c->ob_lat.as<double>() + b0;
+    a.ob_lon = c->ob_lon.as<double>() + b0;
+    a.ob_hw = c->ob_hw.as<double>() + b0;
+    a.skip_lo = b0;
+    a.skip_hi = b0 + nb;
+    a.taper_rows = P;
+    EFA_HIP(launch_sweep(a, s));
+  }
+  EFA_HIP(hipMemcpyAsync(Yp_dev, Yw, (size_t)P * M * sizeof(double), hipMemcpyDeviceToDevice, s));
+  EFA_HIP(hipMemcpyAsync(ym_dev, ymw, dP, hipMemcpyDeviceToDevice, s));
+  if (c->timing) EFA_HIP(hipEventRecord(c->ev[1], s));
+
+  // diagnostics back to the caller (ensrf.py:66,70,75,146-149)
+  c->h_tmp.resize((size_t)P * 2);
+  c->h_tmp8.resize((size_t)P);
+  if (prior_mean) EFA_HIP(hipMemcpyAsync(prior_mean, c->d_prior_mean.p, dP, hipMemcpyDeviceToHost, s));
+  if (prior_var) EFA_HIP(hipMemcpyAsync(prior_var, c->d_prior_var.p, dP, hipMemcpyDeviceToHost, s));
+  EFA_HIP(hipMemcpyAsync(c->h_tmp.data(), c->d_post_mean.p, dP, hipMemcpyDeviceToHost, s));
+  EFA_HIP(hipMemcpyAsync(c->h_tmp.data() + P, c->d_post_var.p, dP, hipMemcpyDeviceToHost, s));
+  EFA_HIP(hipMemcpyAsync(c->h_tmp8.data(), c->d_assimilated.p, (size_t)P, hipMemcpyDeviceToHost, s));
+  EFA_HIP(hipStreamSynchronize(s));
+  for (long k = 0; k < P; ++k) {
+    if (assimilated) assimilated[k] = c->h_tmp8[k];
+    if (c->h_tmp8[k]) {
+      if (post_mean) post_mean[k] = c->h_tmp[k];
+      if (post_var) post_var[k] = c->h_tmp[P + k];
+    }
+  }
+  if (c->timing) {
+    float ms = 0.f;
+    EFA_HIP(hipEventElapsedTime(&ms, c->ev[0], c->ev[1]));
+    c->obs_ms = ms;
+  }
+  c->have_transform = carry_T;
+  c->have_traj = true;
+  return EFA_OK;
+}
+
+bool want_transform(const efa_ctx* c) {
+  if (!c->have_transform) return false;
+  if (c->path == EFA_PATH_TRANSFORM) return true;
+  if (c->path == EFA_PATH_SWEEP) return false;
+  return c->n_active > c->M / 2;  // one pass costs about M/2 observations of sweep arithmetic
+}
+
+int prepare_grid(efa_ctx* c, const double* grid_lat, const double* grid_lon, long ncol, long n_lead, long rows) {
+  if (c->loc_mode != EFA_LOC_GC) return EFA_OK;
+  if (!grid_lat || !grid_lon) return fail(EFA_ERR_INVALID, "GC localisation needs grid_lat/grid_lon");
+  if (ncol <= 0 || n_lead <= 0 || ncol * n_lead != rows)
+    return fail(EFA_ERR_INVALID, "rows=%ld must equal n_lead*ncol = %ld*%ld", rows, n_lead, ncol);
+  EFA_TRY(h2d(c, c->glat, grid_lat, (size_t)ncol * sizeof(double)));
+  EFA_TRY(h2d(c, c->glon, grid_lon, (size_t)ncol * sizeof(double)));
+  EFA_HIP(hipStreamSynchronize(c->stream));  // caller may reuse grid_lat/grid_lon on return
+  return EFA_OK;
+}
+
+// ---- Phase B (perturbation form) ------------------------------------------
+int state_sweeps(efa_ctx* c, long rows, const double* xm_in, const double* Xp_in, double* xm_out, double* Xp_out,
+                 long ncol) {
+  const int M = c->M;
+  const long P = c->P;
+  hipStream_t s = c->stream;
+  const long B = effective_batch(c, M);
+  bool first = true;
+  for (long b0 = 0; b0 < P; b0 += B) {
+    const int nb = (int)((P - b0 < B) ? (P - b0) : B);
+    long act = 0;
+    for (int k = 0; k < nb; ++k) act += c->h_assim[b0 + k] ? 1 : 0;
+    if (act == 0) continue;
+    SweepArgs a{};
+    a.Xin = first ? Xp_in : Xp_out;
+    a.xin = first ? xm_in : xm_out;
+    a.Xout = Xp_out;
+    a.xout = xm_out;
+    a.nrows = rows;
+    a.M = M;
+    a.Ye = c->Ye_rec.as<double>() + (size_t)b0 * M;
+    a.coef = c->coef.as<double>() + (size_t)b0 * kCoefStride;
+    a.nb = nb;
+    a.skip_lo = a.skip_hi = -1;
+    if (c->loc_mode == EFA_LOC_GC) {
+      EFA_TRY(c->W.reserve((size_t)B * ncol * sizeof(double)));
+      EFA_HIP(launch_taper_table(ncol, nb, c->glat.as<double>(), c->glon.as<double>(),
+                                 c->ob_lat.as<double>() + b0, c->ob_lon.as<double>() + b0,
+                                 c->ob_hw.as<double>() + b0, c->W.as<double>(), s));
+      a.taper_mode = kTaperTable;
+      a.W = c->W.as<double>();
+      a.ncol = ncol;
+    } else {
+      a.taper_mode = kTaperNone;
+    }
+    EFA_HIP(launch_sweep(a, s));
+    c->state_launches++;
+    first = false;
+  }
+  if (first && Xp_out != Xp_in) {  // nothing assimilated: posterior == prior
+    EFA_HIP(hipMemcpyAsync(Xp_out, Xp_in, (size_t)rows * M * sizeof(double), hipMemcpyDeviceToDevice, s));
+    EFA_HIP(hipMemcpyAsync(xm_out, xm_in, (size_t)rows * sizeof(double), hipMemcpyDeviceToDevice, s));
+  }
+  return EFA_OK;
+}
+
+int state_phase(efa_ctx* c, long rows, int M, const double* xm_in, const double* Xp_in, double* xm_out,
+                double* Xp_out, const double* grid_lat, const double* grid_lon, long ncol, long n_lead) {
+  if (!c->have_traj) return fail(EFA_ERR_INVALID, "efa_state_phase_dev called before efa_obs_phase_dev");
+  if (M != c->M) return fail(EFA_ERR_INVALID, "M=%d differs from the obs phase's M=%d", M, c->M);
+  if (rows < 0) return fail(EFA_ERR_INVALID, "negative row count");
+  c->state_ms = 0.0;
+  c->state_launches = 0;
+  c->path_taken = EFA_PATH_SWEEP;
+  if (rows == 0) return EFA_OK;
+  if (!xm_in || !Xp_in || !xm_out || !Xp_out) return fail(EFA_ERR_INVALID, "null state pointer");
+  EFA_TRY(prepare_grid(c, grid_lat, grid_lon, ncol, n_lead, rows));
+  hipStream_t s = c->stream;
+  if (c->timing) EFA_HIP(hipEventRecord(c->ev[2], s));
+  if (c->P > 0 && c->n_active > 0 && want_transform(c)) {
+    TransformArgs t{};
+    t.Xin = Xp_in;
+    t.xin = xm_in;
+    t.Xout = Xp_out;
+    t.xout = xm_out;
+    t.nrows = rows;
+    t.M = M;
+    t.T = c->Yw.as<double>() + (size_t)c->P * M;
+    t.w = c->ymw.as<double>() + c->P;
+    t.fused_members = 0;
+    EFA_HIP(launch_transform(t, s));
+    c->state_launches = 1;
+    c->path_taken = EFA_PATH_TRANSFORM;
+  } else {
+    EFA_TRY(state_sweeps(c, rows, xm_in, Xp_in, xm_out, Xp_out, ncol));
+  }
+  if (c->timing) {
+    EFA_HIP(hipEventRecord(c->ev[3], s));
+    EFA_HIP(hipEventSynchronize(c->ev[3]));
+    float ms = 0.f;
+    EFA_HIP(hipEventElapsedTime(&ms, c->ev[2], c->ev[3]));
+    c->state_ms = ms;
+  }
+  return EFA_OK;
+}
+
+}  // namespace
+
+// ===========================================================================
+extern "C" {
+
+int efa_abi_version(void) { return EFA_ABI_VERSION; }
+
+const char* efa_last_error(void) { return g_last_error.c_str(); }
+
+int efa_device_count(int* count) {
+  if (!count) return fail(EFA_ERR_INVALID, "null count");
+  int n = 0;
+  hipError_t e = hipGetDeviceCount(&n);
+  if (e != hipSuccess) {
+    (void)hipGetLastError();
+    n = 0;
+  }
+  *count = n;
+  return EFA_OK;
+}
+
+int efa_ctx_create(int device_id, efa_ctx** out) {
+  if (!out) return fail(EFA_ERR_INVALID, "null out pointer");
+  *out = nullptr;
+  int n = 0;
+  hipError_t e = hipGetDeviceCount(&n);
+  if (e != hipSuccess || n <= 0) {
+    (void)hipGetLastError();
+    return fail(EFA_ERR_NO_DEVICE,
+                "no HIP device visible (%s): libefa_hip has no CPU fallback and needs an MI355X (gfx950)",
+                e != hipSuccess ? hipGetErrorString(e) : "device count 0");
+  }
+  if (device_id < 0 || device_id >= n) return fail(EFA_ERR_INVALID, "device_id %d out of range [0,%d)", device_id, n);
+  hipDeviceProp_t prop;
+  EFA_HIP(hipGetDeviceProperties(&prop, device_id));
+  if (strncmp(prop.gcnArchName, "gfx950", 6) != 0)
+    return fail(EFA_ERR_NO_DEVICE, "device %d is %s; this library is built for gfx950 (MI355X) only", device_id,
+                prop.gcnArchName);
+  EFA_HIP(hipSetDevice(device_id));
+  efa_ctx* c = new (std::nothrow) efa_ctx();
+  if (!c) return fail(EFA_ERR_INVALID, "out of host memory");
+  c->device = device_id;
+  hipError_t es = hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking);
+  if (es != hipSuccess) {
+    delete c;
+    return fail(EFA_ERR_HIP, "hipStreamCreate failed: %s", hipGetErrorString(es));
+  }
+  c->stream = c->own_stream;
+  for (int i = 0; i < 4; ++i) {
+    hipError_t ee = hipEventCreate(&c->ev[i]);
+    if (ee != hipSuccess) {
+      efa_ctx_destroy(c);
+      return fail(EFA_ERR_HIP, "hipEventCreate failed: %s", hipGetErrorString(ee));
+    }
+  }
+  *out = c;
+  return EFA_OK;
+}
+
+int efa_ctx_destroy(efa_ctx* c) {
+  if (!c) return EFA_OK;
+  (void)hipSetDevice(c->device);
+  if (c->stream) (void)hipStreamSynchronize(c->stream);
+  DevBuf* bufs[] = {&c->Ye_rec, &c->coef, &c->ob_val, &c->ob_err, &c->ob_asm, &c->ob_lat, &c->ob_lon, &c->ob_hw,
+                    &c->d_prior_mean, &c->d_prior_var, &c->d_post_mean, &c->d_post_var, &c->d_assimilated,
+                    &c->Yw, &c->ymw, &c->W, &c->glat, &c->glon, &c->xm_ws, &c->h_xm, &c->h_Xp, &c->h_ym, &c->h_Yp};
+  for (DevBuf* b : bufs) b->release();
+  for (int i = 0; i < 4; ++i)
+    if (c->ev[i]) (void)hipEventDestroy(c->ev[i]);
+  if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
+  delete c;
+  return EFA_OK;
+}
+
+int efa_ctx_set_stream(efa_ctx* c, void* hip_stream) {
+  EFA_TRY(use(c));
+  c->stream = hip_stream ? reinterpret_cast<hipStream_t>(hip_stream) : c->own_stream;
+  return EFA_OK;
+}
+
+int efa_ctx_set_option(efa_ctx* c, const char* key, long value) {
+  EFA_TRY(use(c));
+  if (!key) return fail(EFA_ERR_INVALID, "null option key");
+  if (!strcmp(key, "obs_batch")) {
+    if (value < 1 || value > efa::kMaxBatch) return fail(EFA_ERR_INVALID, "obs_batch must be in [1,%d]", efa::kMaxBatch);
+    c->obs_batch = value;
+  } else if (!strcmp(key, "path")) {
+    if (value < EFA_PATH_AUTO || value > EFA_PATH_TRANSFORM) return fail(EFA_ERR_INVALID, "path must be 0,1,2");
+    c->path = value;
+  } else if (!strcmp(key, "timing")) {
+    c->timing = value ? 1 : 0;
+  } else if (!strcmp(key, "threads_hint")) {
+  } else {
+    return fail(EFA_ERR_INVALID, "unknown option '%s'", key);
+  }
+  return EFA_OK;
+}
+
+int efa_ctx_get_option(efa_ctx* c, const char* key, long* value) {
+  EFA_TRY(use(c));
+  if (!key || !value) return fail(EFA_ERR_INVALID, "null argument");
+  if (!strcmp(key, "obs_batch")) *value = c->obs_batch;
+  else if (!strcmp(key, "path")) *value = c->path;
+  else if (!strcmp(key, "timing")) *value = c->timing;
+  else if (!strcmp(key, "device")) *value = c->device;
+  else return fail(EFA_ERR_INVALID, "unknown option '%s'", key);
+  return EFA_OK;
+}
+
+int efa_ctx_synchronize(efa_ctx* c) {
+  EFA_TRY(use(c));
+  EFA_HIP(hipStreamSynchronize(c->stream));
+  return EFA_OK;
+}
+
+int efa_malloc(efa_ctx* c, size_t bytes, void** dev_out) {
+  EFA_TRY(use(c));
+  if (!dev_out) return fail(EFA_ERR_INVALID, "null out pointer");
+  *dev_out = nullptr;
+  EFA_HIP(hipMalloc(dev_out, bytes ? bytes : 8));
+  return EFA_OK;
+}
+
+int efa_free(efa_ctx* c, void* dev) {
+  EFA_TRY(use(c));
+  if (dev) EFA_HIP(hipFree(dev));
+  return EFA_OK;
+}
+
+int efa_memcpy_h2d(efa_ctx* c, void* dst_dev, const void* src, size_t bytes) {
+  EFA_TRY(use(c));
+  if (bytes) {
+    EFA_HIP(hipMemcpyAsync(dst_dev, src, bytes, hipMemcpyHostToDevice, c->stream));
+    EFA_HIP(hipStreamSynchronize(c->stream));
+  }
+  return EFA_OK;
+}
+
+int efa_memcpy_d2h(efa_ctx* c, void* dst, const void* src_dev, size_t bytes) {
+  EFA_TRY(use(c));
+  if (bytes) {
+    EFA_HIP(hipMemcpyAsync(dst, src_dev, bytes, hipMemcpyDeviceToHost, c->stream));
+    EFA_HIP(hipStreamSynchronize(c->stream));
+  }
+  return EFA_OK;
+}
+
+int efa_memcpy_d2d(efa_ctx* c, void* dst_dev, const void* src_dev, size_t bytes) {
+  EFA_TRY(use(c));
+  if (bytes) EFA_HIP(hipMemcpyAsync(dst_dev, src_dev, bytes, hipMemcpyDeviceToDevice, c->stream));
+  return EFA_OK;
+}
+
+int efa_form_perts_dev(efa_ctx* c, long rows, int M, const double* X_dev, double scale, double* xm_dev,
+                       double* Xp_dev) {
+  EFA_TRY(use(c));
+  if (rows < 0 || M < 1 || M > efa::kMaxMembers) return fail(EFA_ERR_INVALID, "bad shape rows=%ld M=%d", rows, M);
+  if (rows && (!X_dev || !xm_dev || !Xp_dev)) return fail(EFA_ERR_INVALID, "null pointer");
+  EFA_HIP(efa::launch_form_perts(rows, M, X_dev, scale, xm_dev, Xp_dev, c->stream));
+  return EFA_OK;
+}
+
+int efa_posterior_dev(efa_ctx* c, long rows, int M, const double* xm_dev, const double* Xp_dev, double* post_dev) {
+  EFA_TRY(use(c));
+  if (rows < 0 || M < 1) return fail(EFA_ERR_INVALID, "bad shape rows=%ld M=%d", rows, M);
+  if (rows && (!xm_dev || !Xp_dev || !post_dev)) return fail(EFA_ERR_INVALID, "null pointer");
+  EFA_HIP(efa::launch_posterior(rows, M, xm_dev, Xp_dev, post_dev, c->stream));
+  return EFA_OK;
+}
+
+int efa_forward_stencil_dev(efa_ctx* c, long rows, long row_offset, int M, const double* X_dev, long P, int npt,
+                            const int64_t* idx, const double* wts, double* HX_dev) {
+  EFA_TRY(use(c));
+  if (rows < 0 || M < 1 || P < 0 || npt < 1) return fail(EFA_ERR_INVALID, "bad shape");
+  if (P == 0) return EFA_OK;
+  if (!X_dev || !idx || !wts || !HX_dev) return fail(EFA_ERR_INVALID, "null pointer");
+  DevBuf di, dw;  // per-call staging; freed on return
+  const size_t n = (size_t)P * npt;
+  int st = di.reserve(n * sizeof(int64_t));
+  if (st == EFA_OK) st = dw.reserve(n * sizeof(double));
+  if (st == EFA_OK) {
+    hipError_t e = hipMemcpyAsync(di.p, idx, n * sizeof(int64_t), hipMemcpyHostToDevice, c->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(dw.p, wts, n * sizeof(double), hipMemcpyHostToDevice, c->stream);
+    if (e == hipSuccess)
+      e = efa::launch_forward_stencil(rows, row_offset, M, X_dev, P, npt, di.as<int64_t>(), dw.as<double>(), HX_dev,
+                                      c->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    if (e != hipSuccess) st = fail(EFA_ERR_HIP, "forward stencil failed: %s", hipGetErrorString(e));
+  }
+  di.release();
+  dw.release();
+  return st;
+}
+
+int efa_obs_phase_dev(efa_ctx* c, int M, long P, double* ym_dev, double* Yp_dev, const double* ob_value,
+                      const double* ob_error, const uint8_t* ob_assim, int loc_mode, const double* ob_lat,
+                      const double* ob_lon, const double* ob_halfwidth_km, double* prior_mean, double* prior_var,
+                      double* post_mean, double* post_var, uint8_t* assimilated) {
+  EFA_TRY(use(c));
+  return obs_phase(c, M, P, ym_dev, Yp_dev, ob_value, ob_error, ob_assim, loc_mode, ob_lat, ob_lon, ob_halfwidth_km,
+                   prior_mean, prior_var, post_mean, post_var, assimilated);
+}
+
+int efa_state_phase_dev(efa_ctx* c, long rows, int M, const double* xm_in_dev, const double* Xp_in_dev,
+                        double* xm_out_dev, double* Xp_out_dev, const double* grid_lat, const double* grid_lon,
+                        long ncol, long n_lead) {
+  EFA_TRY(use(c));
+  return state_phase(c, rows, M, xm_in_dev, Xp_in_dev, xm_out_dev, Xp_out_dev, grid_lat, grid_lon, ncol, n_lead);
+}
+
+int efa_state_cycle_dev(efa_ctx* c, long rows, int M, const double* X_dev, double* post_dev, const double* grid_lat,
+                        const double* grid_lon, long ncol, long n_lead) {
+  EFA_TRY(use(c));
+  if (!c->have_traj) return fail(EFA_ERR_INVALID, "efa_state_cycle_dev called before efa_obs_phase_dev");
+  if (M != c->M) return fail(EFA_ERR_INVALID, "M=%d differs from the obs phase's M=%d", M, c->M);
+  c->state_ms = 0.0;
+  c->state_launches = 0;
+  c->path_taken = EFA_PATH_SWEEP;
+  if (rows <= 0) return rows == 0 ? EFA_OK : fail(EFA_ERR_INVALID, "negative row count");
+  if (!X_dev || !post_dev) return fail(EFA_ERR_INVALID, "null state pointer");
+  EFA_TRY(prepare_grid(c, grid_lat, grid_lon, ncol, n_lead, rows));
+  hipStream_t s = c->stream;
+  if (c->timing) EFA_HIP(hipEventRecord(c->ev[2], s));
+  if (c->P > 0 && c->n_active > 0 && want_transform(c)) {
+    efa::TransformArgs t{};
+    t.Xin = X_dev;
+    t.Xout = post_dev;
+    t.nrows = rows;
+    t.M = M;
+    t.T = c->Yw.as<double>() + (size_t)c->P * M;
+    t.w = c->ymw.as<double>() + c->P;
+    t.fused_members = 1;
+    EFA_HIP(efa::launch_transform(t, s));
+    c->state_launches = 1;
+    c->path_taken = EFA_PATH_TRANSFORM;
+  } else {
+    EFA_TRY(c->xm_ws.reserve((size_t)rows * sizeof(double)));
+    double* xm = c->xm_ws.as<double>();
+    EFA_HIP(efa::launch_form_perts(rows, M, X_dev, 1.0, xm, post_dev, s));
+    EFA_TRY(state_sweeps(c, rows, xm, post_dev, xm, post_dev, ncol));
+    EFA_HIP(efa::launch_posterior(rows, M, xm, post_dev, post_dev, s));
+  }
+  if (c->timing) {
+    EFA_HIP(hipEventRecord(c->ev[3], s));
+    EFA_HIP(hipEventSynchronize(c->ev[3]));
+    float ms = 0.f;
+    EFA_HIP(hipEventElapsedTime(&ms, c->ev[2], c->ev[3]));
+    c->state_ms = ms;
+  }
+  return EFA_OK;
+}
+
+int efa_ensrf_update_dev(efa_ctx* c, long rows, int M, long P, double* xm_dev, double* Xp_dev, double* ym_dev,
+                         double* Yp_dev, const double* ob_value, const double* ob_error, const uint8_t* ob_assim,
+                         int loc_mode, const double* ob_lat, const double* ob_lon, const double* ob_halfwidth_km,
+                         const double* grid_lat, const double* grid_lon, long ncol, long n_lead, double* prior_mean,
+                         double* prior_var, double* post_mean, double* post_var, uint8_t* assimilated) {
+  EFA_TRY(use(c));
+  EFA_TRY(obs_phase(c, M, P, ym_dev, Yp_dev, ob_value, ob_error, ob_assim, loc_mode, ob_lat, ob_lon,
+                    ob_halfwidth_km, prior_mean, prior_var, post_mean, post_var, assimilated));
+  EFA_TRY(state_phase(c, rows, M, xm_dev, Xp_dev, xm_dev, Xp_dev, grid_lat, grid_lon, ncol, n_lead));
+  EFA_HIP(hipStreamSynchronize(c->stream));
+  return EFA_OK;
+}
+
+int efa_ensrf_update(efa_ctx* c, long A, long N, int M, long P, double* xbm, double* Xbp, const double* ob_value,
+                     const double* ob_error, const uint8_t* ob_assim, int loc_mode, const double* ob_lat,
+                     const double* ob_lon, const double* ob_halfwidth_km, const double* grid_lat,
+                     const double* grid_lon, long ncol, long n_lead, double* prior_mean, double* prior_var,
+                     double* post_mean, double* post_var, uint8_t* assimilated) {
+  EFA_TRY(use(c));
+  if (N < 0 || P < 0 || A != N + P) return fail(EFA_ERR_INVALID, "A=%ld must equal N+P=%ld+%ld", A, N, P);
+  EFA_TRY(check_common(M, P));
+  if (A && (!xbm || !Xbp)) return fail(EFA_ERR_INVALID, "null xbm/Xbp");
+  const size_t rowb = (size_t)M * sizeof(double);
+  EFA_TRY(c->h_xm.reserve((size_t)(N ? N : 1) * sizeof(double)));
+  EFA_TRY(c->h_Xp.reserve((size_t)(N ? N : 1) * rowb));
+  EFA_TRY(c->h_ym.reserve((size_t)(P ? P : 1) * sizeof(double)));
+  EFA_TRY(c->h_Yp.reserve((size_t)(P ? P : 1) * rowb));
+  hipStream_t s = c->stream;
+  if (N) {
+    EFA_HIP(hipMemcpyAsync(c->h_xm.p, xbm, (size_t)N * sizeof(double), hipMemcpyHostToDevice, s));
+    EFA_HIP(hipMemcpyAsync(c->h_Xp.p, Xbp, (size_t)N * rowb, hipMemcpyHostToDevice, s));
+  }
+  if (P) {
+    EFA_HIP(hipMemcpyAsync(c->h_ym.p, xbm + N, (size_t)P * sizeof(double), hipMemcpyHostToDevice, s));
+    EFA_HIP(hipMemcpyAsync(c->h_Yp.p, Xbp + (size_t)N * M, (size_t)P * rowb, hipMemcpyHostToDevice, s));
+  }
+  EFA_TRY(efa_ensrf_update_dev(c, N, M, P, c->h_xm.as<double>(), c->h_Xp.as<double>(), c->h_ym.as<double>(),
+                               c->h_Yp.as<double>(), ob_value, ob_error, ob_assim, loc_mode, ob_lat, ob_lon,
+                               ob_halfwidth_km, grid_lat, grid_lon, ncol, n_lead, prior_mean, prior_var, post_mean,
+                               post_var, assimilated));
+  if (N) {
+    EFA_HIP(hipMemcpyAsync(xbm, c->h_xm.p, (size_t)N * sizeof(double), hipMemcpyDeviceToHost, s));
+    EFA_HIP(hipMemcpyAsync(Xbp, c->h_Xp.p, (size_t)N * rowb, hipMemcpyDeviceToHost, s));
+  }
+  if (P) {
+    EFA_HIP(hipMemcpyAsync(xbm + N, c->h_ym.p, (size_t)P * sizeof(double), hipMemcpyDeviceToHost, s));
+    EFA_HIP(hipMemcpyAsync(Xbp + (size_t)N * M, c->h_Yp.p, (size_t)P * rowb, hipMemcpyDeviceToHost, s));
+  }
+  EFA_HIP(hipStreamSynchronize(s));
+  return EFA_OK;
+}
+
+int efa_last_timing(efa_ctx* c, double* state_ms, double* obs_ms, long* state_launches, int* path_taken) {
+  if (!c) return fail(EFA_ERR_INVALID, "null context");
+  if (state_ms) *state_ms = c->state_ms;
+  if (obs_ms) *obs_ms = c->obs_ms;
+  if (state_launches) *state_launches = c->state_launches;
+  if (path_taken) *path_taken = c->path_taken;
+  return EFA_OK;
+}
+
+int efa_fill_synthetic_dev(efa_ctx* c, long rows, long row_offset, int M, uint64_t seed, double sigma,
+                           double* X_dev) {
+  EFA_TRY(use(c));
+  if (rows < 0 || M < 1) return fail(EFA_ERR_INVALID, "bad shape");
+  if (rows && !X_dev) return fail(EFA_ERR_INVALID, "null pointer");
+  EFA_HIP(efa::launch_fill_synthetic(rows, row_offset, M, seed, sigma, X_dev, c->stream));
+  return EFA_OK;
+}
+
+}  // extern "C"

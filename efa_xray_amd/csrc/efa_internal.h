@@ -1,0 +1,102 @@
+// Internal interfaces between the C-ABI layer (efa_capi.hip) and the kernel
+// translation units.  Nothing here is exported.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace efa {
+
+// Largest ensemble the register-resident kernels are instantiated for.
+constexpr int kMaxMembers = 256;
+// Rows (observations) handled by one obs-space diag workgroup == max obs_batch.
+constexpr int kMaxBatch = 64;
+
+// Per-observation coefficients recorded by Phase A (4 doubles per ob):
+//   [0] innov   = ob.value - mye                     (ensrf.py:85)
+//   [1] rden    = 1 / (varye + ob.error)             (ensrf.py:91,119)
+//   [2] beta    = 1/(1+sqrt(err/(varye+err)))        (ensrf.py:135)
+//   [3] active  = 1.0 if ob.assimilate_this else 0.0 (ensrf.py:74)
+constexpr int kCoefStride = 4;
+
+enum TaperMode : int {
+  kTaperNone = 0,   // loc in (None, False)
+  kTaperTable = 1,  // state rows: W[k][col] precomputed per batch (2-D taper, ensrf.py:108-111)
+  kTaperObs = 2     // obs rows: haversine between observations, in-kernel (ensrf.py:113)
+};
+
+struct SweepArgs {
+  const double* Xin;   // [nrows][M] perturbation rows (may alias Xout)
+  const double* xin;   // [nrows]   means
+  double* Xout;
+  double* xout;
+  long nrows;
+  int M;
+  const double* Ye;    // [nb][M] recorded obs-space perturbations of the batch
+  const double* coef;  // [nb][kCoefStride]
+  int nb;
+  int taper_mode;
+  const double* W;     // kTaperTable: [nb][ncol]
+  long ncol;
+  const double* row_lat;  // kTaperObs: lat/lon of the ob each swept row belongs to [nrows]
+  const double* row_lon;
+  const double* ob_lat;   // kTaperObs: lat/lon/halfwidth of the batch obs [nb]
+  const double* ob_lon;
+  const double* ob_hw;
+  long skip_lo, skip_hi;  // rows in [skip_lo, skip_hi) are not touched
+  long taper_rows;        // kTaperObs applies to rows < taper_rows (extra rows: weight 1)
+};
+
+struct DiagArgs {
+  double* Yp;  // [P(+extra)][M] obs block perturbations (in/out)
+  double* ym;  // [P(+extra)]    obs block means (in/out)
+  int M;
+  long b0;  // first ob of the batch
+  int nb;   // obs in the batch (<= kMaxBatch)
+  const double* ob_value;  // device [P]
+  const double* ob_error;
+  const uint8_t* ob_assim;
+  int loc_mode;
+  const double* ob_lat;
+  const double* ob_lon;
+  const double* ob_hw;
+  double* Ye_rec;  // [P][M] out: ye of ob k at the moment it is assimilated
+  double* coef;    // [P][kCoefStride] out
+  double* prior_mean;  // device [P] out
+  double* prior_var;
+  double* post_mean;
+  double* post_var;
+  uint8_t* assimilated;
+};
+
+struct TransformArgs {
+  const double* Xin;  // [rows][M] perturbations, or full members when fused_members
+  const double* xin;  // [rows] means (unused when fused_members)
+  double* Xout;       // [rows][M]
+  double* xout;       // [rows] (unused when fused_members)
+  long nrows;
+  int M;
+  const double* T;  // [M][M] row-major: Xap = Xbp * T
+  const double* w;  // [M]:             xam = xbm + Xbp * w
+  int fused_members;  // 1: Xin holds prior members, Xout receives posterior members
+};
+
+hipError_t launch_sweep(const SweepArgs& a, hipStream_t s);
+hipError_t launch_diag(const DiagArgs& a, hipStream_t s);
+hipError_t launch_transform(const TransformArgs& a, hipStream_t s);
+bool transform_supported(int M);
+
+hipError_t launch_form_perts(long rows, int M, const double* X, double scale, double* xm,
+                             double* Xp, hipStream_t s);
+hipError_t launch_posterior(long rows, int M, const double* xm, const double* Xp, double* post,
+                            hipStream_t s);
+hipError_t launch_taper_table(long ncol, int nb, const double* grid_lat, const double* grid_lon,
+                              const double* ob_lat, const double* ob_lon, const double* ob_hw,
+                              double* W, hipStream_t s);
+hipError_t launch_forward_stencil(long rows, long row_offset, int M, const double* X, long P,
+                                  int npt, const int64_t* idx, const double* wts, double* HX,
+                                  hipStream_t s);
+hipError_t launch_fill_synthetic(long rows, long row_offset, int M, uint64_t seed, double sigma,
+                                 double* X, hipStream_t s);
+hipError_t launch_set_identity(int M, double* T, double* w, hipStream_t s);
+
+}  // namespace efa

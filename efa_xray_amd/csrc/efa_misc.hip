@@ -1,0 +1,176 @@
+// Streaming helper kernels around the hot loop: perturbation formation (a3),
+// posterior rebuild (a15), per-batch Gaspari-Cohn taper table (a10), the linear
+// forward-operator stencil (f1) and the bench's synthetic-ensemble generator.
+#include "efa_device.h"
+#include "efa_internal.h"
+
+namespace efa {
+namespace {
+
+constexpr int kThreads = 256;
+
+// One wave per row: lane l handles members l, l+64, ...  Rows are contiguous
+// so a wave reads/writes M*8 contiguous bytes per row (coalesced).
+// xm = mean over members (assimilation.py:146), Xp = scale*(X - xm) (:147, :67).
+__global__ __launch_bounds__(kThreads) void k_form_perts(long rows, int M, const double* __restrict__ X,
+                                                         double scale, double* __restrict__ xm,
+                                                         double* __restrict__ Xp) {
+  const int lane = threadIdx.x & 63;
+  const long wave = (long)blockIdx.x * (kThreads / 64) + (threadIdx.x >> 6);
+  const long nwaves = (long)gridDim.x * (kThreads / 64);
+  for (long row = wave; row < rows; row += nwaves) {
+    const double* p = X + (size_t)row * M;
+    double v[4];
+    double s = 0.0;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int m = lane + 64 * j;
+      v[j] = (m < M) ? p[m] : 0.0;
+      s += v[j];
+    }
+    const double mean = wave_sum(s) / (double)M;
+    double* o = Xp + (size_t)row * M;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int m = lane + 64 * j;
+      if (m < M) o[m] = (scale == 1.0) ? (v[j] - mean) : (v[j] - mean) * scale;
+    }
+    if (lane == 0) xm[row] = mean;
+  }
+}
+
+// post = xam[:,None] + Xap (assimilation.py:168); flat, 2 doubles per lane.
+__global__ __launch_bounds__(kThreads) void k_posterior(long rows, int M, const double* __restrict__ xm,
+                                                        const double* __restrict__ Xp,
+                                                        double* __restrict__ post) {
+  const size_t total = (size_t)rows * M;
+  const size_t stride = (size_t)gridDim.x * kThreads;
+  for (size_t i = (size_t)blockIdx.x * kThreads + threadIdx.x; i < total; i += stride) {
+    const size_t row = i / M;
+    post[i] = xm[row] + Xp[i];
+  }
+}
+
+// W[k][col] = GC(distance_to_point(grid[col], ob_k) / halfwidth_k)
+// (observation.py:59-87 on an EnsembleState; the caller broadcasts it over
+// var x time, ensrf.py:108-111 -- here by indexing col = row % ncol).
+__global__ __launch_bounds__(kThreads) void k_taper_table(long ncol, int nb, const double* __restrict__ glat,
+                                                          const double* __restrict__ glon,
+                                                          const double* __restrict__ ob_lat,
+                                                          const double* __restrict__ ob_lon,
+                                                          const double* __restrict__ ob_hw,
+                                                          double* __restrict__ W) {
+  const size_t total = (size_t)ncol * nb;
+  const size_t stride = (size_t)gridDim.x * kThreads;
+  for (size_t i = (size_t)blockIdx.x * kThreads + threadIdx.x; i < total; i += stride) {
+    const int k = (int)(i / ncol);
+    const long c = (long)(i - (size_t)k * ncol);
+    const double d = distance_to_point_km(glat[c], glon[c], ob_lat[k], ob_lon[k]);
+    W[i] = gaspari_cohn(d, ob_hw[k]);
+  }
+}
+
+// HX[k,:] = sum_j w[k,j] * X[idx[k,j]-row_offset,:] over locally owned points.
+__global__ __launch_bounds__(kThreads) void k_forward_stencil(long rows, long row_offset, int M,
+                                                              const double* __restrict__ X, long P,
+                                                              int npt, const int64_t* __restrict__ idx,
+                                                              const double* __restrict__ wts,
+                                                              double* __restrict__ HX) {
+  const size_t total = (size_t)P * M;
+  const size_t stride = (size_t)gridDim.x * kThreads;
+  for (size_t i = (size_t)blockIdx.x * kThreads + threadIdx.x; i < total; i += stride) {
+    const long k = (long)(i / M);
+    const int m = (int)(i - (size_t)k * M);
+    double acc = 0.0;
+    bool first = true;
+    for (int j = 0; j < npt; ++j) {
+      const double w = wts[(size_t)k * npt + j];
+      const long g = idx[(size_t)k * npt + j] - row_offset;
+      if (w == 0.0 || g < 0 || g >= rows) continue;
+      const double t = w * X[(size_t)g * M + m];
+      acc = first ? t : acc + t;
+      first = false;
+    }
+    HX[i] = acc;
+  }
+}
+
+__global__ __launch_bounds__(kThreads) void k_fill_synthetic(long rows, long row_offset, int M,
+                                                             uint64_t seed, double sigma,
+                                                             double* __restrict__ X) {
+  const size_t total = (size_t)rows * M;
+  const size_t stride = (size_t)gridDim.x * kThreads;
+  for (size_t i = (size_t)blockIdx.x * kThreads + threadIdx.x; i < total; i += stride) {
+    const uint64_t row = (uint64_t)(i / M) + (uint64_t)row_offset;
+    const uint64_t m = (uint64_t)(i % M);
+    const double mu = normal_from(mix64(seed ^ 0xA5A5A5A5ull) + row * 0x100000001B3ull);
+    const double z = normal_from(mix64(seed) + row * 1099511628211ull + m * 0x9E3779B97F4A7C15ull);
+    X[i] = mu + sigma * z;
+  }
+}
+
+__global__ void k_set_identity(int M, double* __restrict__ T, double* __restrict__ w) {
+  const int total = M * M;
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x)
+    T[i] = (i / M == i % M) ? 1.0 : 0.0;
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < M; i += gridDim.x * blockDim.x) w[i] = 0.0;
+}
+
+inline unsigned grid_for(size_t work_items, int per_block) {
+  size_t g = (work_items + per_block - 1) / per_block;
+  const size_t cap = 256u * 8u;
+  if (g > cap) g = cap;
+  if (g < 1) g = 1;
+  return (unsigned)g;
+}
+
+}  // namespace
+
+hipError_t launch_form_perts(long rows, int M, const double* X, double scale, double* xm, double* Xp,
+                             hipStream_t s) {
+  if (M < 1 || M > kMaxMembers) return hipErrorInvalidValue;
+  if (rows <= 0) return hipSuccess;
+  hipLaunchKernelGGL(k_form_perts, dim3(grid_for((size_t)rows, kThreads / 64)), dim3(kThreads), 0, s, rows, M,
+                     X, scale, xm, Xp);
+  return hipGetLastError();
+}
+
+hipError_t launch_posterior(long rows, int M, const double* xm, const double* Xp, double* post,
+                            hipStream_t s) {
+  if (rows <= 0) return hipSuccess;
+  hipLaunchKernelGGL(k_posterior, dim3(grid_for((size_t)rows * M, kThreads)), dim3(kThreads), 0, s, rows, M,
+                     xm, Xp, post);
+  return hipGetLastError();
+}
+
+hipError_t launch_taper_table(long ncol, int nb, const double* grid_lat, const double* grid_lon,
+                              const double* ob_lat, const double* ob_lon, const double* ob_hw, double* W,
+                              hipStream_t s) {
+  if (ncol <= 0 || nb <= 0) return hipSuccess;
+  hipLaunchKernelGGL(k_taper_table, dim3(grid_for((size_t)ncol * nb, kThreads)), dim3(kThreads), 0, s, ncol,
+                     nb, grid_lat, grid_lon, ob_lat, ob_lon, ob_hw, W);
+  return hipGetLastError();
+}
+
+hipError_t launch_forward_stencil(long rows, long row_offset, int M, const double* X, long P, int npt,
+                                  const int64_t* idx, const double* wts, double* HX, hipStream_t s) {
+  if (P <= 0) return hipSuccess;
+  hipLaunchKernelGGL(k_forward_stencil, dim3(grid_for((size_t)P * M, kThreads)), dim3(kThreads), 0, s, rows,
+                     row_offset, M, X, P, npt, idx, wts, HX);
+  return hipGetLastError();
+}
+
+hipError_t launch_fill_synthetic(long rows, long row_offset, int M, uint64_t seed, double sigma, double* X,
+                                 hipStream_t s) {
+  if (rows <= 0) return hipSuccess;
+  hipLaunchKernelGGL(k_fill_synthetic, dim3(grid_for((size_t)rows * M, kThreads)), dim3(kThreads), 0, s, rows,
+                     row_offset, M, seed, sigma, X);
+  return hipGetLastError();
+}
+
+hipError_t launch_set_identity(int M, double* T, double* w, hipStream_t s) {
+  hipLaunchKernelGGL(k_set_identity, dim3(16), dim3(256), 0, s, M, T, w);
+  return hipGetLastError();
+}
+
+}  // namespace efa

@@ -1,0 +1,227 @@
+// Unlocalised collapse of the serial EnSRF loop into one pass over the state.
+//
+// With loc in (None, False) every row of the reference's update
+//   kcov_i = Xbp_i . ye_k/(Nens-1); xam_i += kcov_i/kdenom*innov;
+//   Xap_i  = Xbp_i - beta*kcov_i/kdenom * ye_k          (ensrf.py:95-141)
+// is the same linear map of that row for all i, so after P observations
+//   Xap = Xbp * T        (T: M x M)      xam = xbm + Xbp * w    (w: M)
+// where (T, w) are what the loop does to the rows of the identity matrix
+// (carried through Phase A as M extra rows of the obs block).  This kernel
+// applies [T | w] to every state row: one HBM read and one write of the state
+// for the whole assimilation cycle.
+//
+// It is a (rows x M) . (M x (M+1)) float64 contraction, done on the matrix
+// cores with v_mfma_f64_16x16x4_f64:
+//   - a wave owns a tile of 16 consecutive rows (contiguous in memory);
+//   - lane l = (g = l>>4, n = l&15) loads members {8u+2g, 8u+2g+1} of row n with
+//     16-byte global loads (a quad of lane-groups covers 64 contiguous bytes);
+//     the K order of the contraction is permuted to match, so the A operand
+//     goes HBM -> VGPR -> MFMA with no LDS staging;
+//   - [T | w] lives in LDS (once per workgroup), pre-arranged so each MFMA's B
+//     operand is one conflict-free ds_read_b64 per lane;
+//   - the next tile's rows are prefetched while the current tile is multiplied.
+#include "efa_device.h"
+#include "efa_internal.h"
+
+namespace efa {
+namespace {
+
+typedef double v4f64 __attribute__((ext_vector_type(4)));
+
+constexpr int kThreadsT = 512;  // 8 waves: two per SIMD share the workgroup's LDS copy of [T|w]
+
+template <int NU>
+struct TShape {
+  static constexpr int NT = NU / 2 + 1;          // 16*NT >= M+1 for every M <= 8*NU
+  static constexpr int kSteps = 2 * NU;          // K steps of 4 members
+  static constexpr size_t lds_doubles = (size_t)kSteps * NT * 64;
+};
+
+template <int NU>
+__device__ __forceinline__ void load_tile(const double* __restrict__ X, long row, bool row_ok, int M, int g,
+                                          double (&a)[2 * NU]) {
+  const double* p = X + (size_t)row * M;
+#pragma unroll
+  for (int u = 0; u < NU; ++u) {
+    const int m0 = 8 * u + 2 * g;
+    if (row_ok && m0 < M) {
+      const double2 v = *reinterpret_cast<const double2*>(p + m0);
+      a[2 * u] = v.x;
+      a[2 * u + 1] = v.y;
+    } else {
+      a[2 * u] = 0.0;
+      a[2 * u + 1] = 0.0;
+    }
+  }
+}
+
+template <int NU>
+__global__ __launch_bounds__(kThreadsT) void k_transform(const TransformArgs p) {
+  using Sh = TShape<NU>;
+  constexpr int NT = Sh::NT;
+  extern __shared__ __align__(16) double Bs[];  // [(u*2+h)*NT + t][64]
+  const int M = p.M;
+  const int tid = threadIdx.x;
+
+  // Stage [T | w] in MFMA-B order: Bs[step s=(u,h)][t][lane (g,n)] = Text[8u+2g+h][16t+n]
+  for (int i = tid; i < (int)Sh::lds_doubles; i += kThreadsT) {
+    const int l = i & 63;
+    const int st = i >> 6;
+    const int t = st % NT;
+    const int s = st / NT;
+    const int u = s >> 1, h = s & 1;
+    const int g = l >> 4, n = l & 15;
+    const int m = 8 * u + 2 * g + h;
+    const int j = 16 * t + n;
+    double v = 0.0;
+    if (m < M) {
+      if (j < M) v = p.T[(size_t)m * M + j];
+      else if (j == M) v = p.w[m];
+    }
+    Bs[i] = v;
+  }
+  __syncthreads();
+
+  const int lane = tid & 63;
+  const int g = lane >> 4, n = lane & 15;
+  const long ntiles = (p.nrows + 15) / 16;
+  const long wave = (long)blockIdx.x * (kThreadsT / 64) + (tid >> 6);
+  const long nwaves = (long)gridDim.x * (kThreadsT / 64);
+  const int tM = M >> 4, nM = M & 15;  // tile / lane column holding the mean increment
+
+  double a[2 * NU], an[2 * NU];
+  long tile = wave;
+  if (tile < ntiles) load_tile<NU>(p.Xin, tile * 16 + n, tile * 16 + n < p.nrows, M, g, a);
+
+  while (tile < ntiles) {
+    const long next = tile + nwaves;
+    if (next < ntiles) load_tile<NU>(p.Xin, next * 16 + n, next * 16 + n < p.nrows, M, g, an);
+    const long r0 = tile * 16;
+
+    double rmean = 0.0;  // prior mean of row n (fused_members only)
+    if (p.fused_members) {
+      double s = 0.0;
+#pragma unroll
+      for (int c = 0; c < 2 * NU; ++c) s += a[c];
+      s += __shfl_xor(s, 16, 64);
+      s += __shfl_xor(s, 32, 64);
+      rmean = s / (double)M;
+#pragma unroll
+      for (int u = 0; u < NU; ++u) {
+        const int m0 = 8 * u + 2 * g;
+        if (m0 < M) a[2 * u] -= rmean;
+        if (m0 + 1 < M) a[2 * u + 1] -= rmean;
+      }
+    }
+
+    v4f64 acc[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) acc[t] = (v4f64){0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+    for (int s = 0; s < 2 * NU; ++s) {
+#pragma unroll
+      for (int t = 0; t < NT; ++t) {
+        const double b = Bs[((size_t)s * NT + t) * 64 + lane];
+        acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[s], b, acc[t], 0, 0, 0);
+      }
+      // keep the scheduler from hoisting all 2*NU*NT LDS reads (register blow-up)
+      if ((s & 1) == 1) __builtin_amdgcn_sched_barrier(0);
+    }
+
+    // acc[t][v] = D[row 4g+v][col 16t+n]
+    double dm[4];  // mean increment of rows 4g+v : column M of the product
+#pragma unroll
+    for (int v = 0; v < 4; ++v) dm[v] = 0.0;
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+      if (t == tM) {
+#pragma unroll
+        for (int v = 0; v < 4; ++v) dm[v] = __shfl(acc[t][v], (lane & 48) | nM, 64);
+      }
+    }
+    double base[4];
+#pragma unroll
+    for (int v = 0; v < 4; ++v) {
+      const long row = r0 + 4 * g + v;
+      double m0;
+      if (p.fused_members) m0 = __shfl(rmean, 4 * g + v, 64);
+      else m0 = (row < p.nrows) ? p.xin[row] : 0.0;
+      base[v] = m0 + dm[v];
+    }
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+      const int col = 16 * t + n;
+      if (col < M) {
+#pragma unroll
+        for (int v = 0; v < 4; ++v) {
+          const long row = r0 + 4 * g + v;
+          if (row < p.nrows) {
+            const double val = p.fused_members ? (base[v] + acc[t][v]) : acc[t][v];
+            p.Xout[(size_t)row * M + col] = val;
+          }
+        }
+      }
+    }
+    if (!p.fused_members && n == 0) {
+#pragma unroll
+      for (int v = 0; v < 4; ++v) {
+        const long row = r0 + 4 * g + v;
+        if (row < p.nrows) p.xout[row] = base[v];
+      }
+    }
+
+#pragma unroll
+    for (int c = 0; c < 2 * NU; ++c) a[c] = an[c];
+    tile = next;
+  }
+}
+
+template <int NU>
+hipError_t transform_nu(const TransformArgs& a, hipStream_t s) {
+  using Sh = TShape<NU>;
+  const size_t lds = Sh::lds_doubles * sizeof(double);
+  if (lds > 64 * 1024) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_transform<NU>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return e;
+  }
+  const long ntiles = (a.nrows + 15) / 16;
+  const int per_cu = (lds <= 80 * 1024) ? 2 : 1;
+  long grid = (ntiles + 7) / 8;
+  if (grid > 256L * per_cu) grid = 256L * per_cu;
+  if (grid < 1) grid = 1;
+  hipLaunchKernelGGL((k_transform<NU>), dim3((unsigned)grid), dim3(kThreadsT), lds, s, a);
+  return hipGetLastError();
+}
+
+}  // namespace
+
+bool transform_supported(int M) { return M >= 2 && M <= 128 && (M % 2 == 0); }
+
+hipError_t launch_transform(const TransformArgs& a, hipStream_t s) {
+  if (!transform_supported(a.M)) return hipErrorInvalidValue;
+  if ((reinterpret_cast<uintptr_t>(a.Xin) & 15u) != 0) return hipErrorInvalidValue;
+  if (a.nrows <= 0) return hipSuccess;
+  const int nu = (a.M + 7) / 8;
+  switch (nu) {
+    case 1: return transform_nu<1>(a, s);
+    case 2: return transform_nu<2>(a, s);
+    case 3: return transform_nu<3>(a, s);
+    case 4: return transform_nu<4>(a, s);
+    case 5: return transform_nu<5>(a, s);
+    case 6: return transform_nu<6>(a, s);
+    case 7: return transform_nu<7>(a, s);
+    case 8: return transform_nu<8>(a, s);
+    case 9: return transform_nu<9>(a, s);
+    case 10: return transform_nu<10>(a, s);
+    case 11: return transform_nu<11>(a, s);
+    case 12: return transform_nu<12>(a, s);
+    case 13: return transform_nu<13>(a, s);
+    case 14: return transform_nu<14>(a, s);
+    case 15: return transform_nu<15>(a, s);
+    case 16: return transform_nu<16>(a, s);
+    default: return hipErrorInvalidValue;
+  }
+}
+
+}  // namespace efa

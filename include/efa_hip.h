@@ -1,0 +1,218 @@
+/*
+ * efa_hip.h -- C ABI of libefa_hip.so: the MI355X (gfx950) implementation of
+ * efa_xray's serial EnSRF assimilation update.
+ *
+ * Boundary.  The reference (lmadaus/efa_xray) has no FFI; its seam is the
+ * `Assimilation` subclass contract
+ *     EnSRF(state, obs, nproc=1, inflation=None, verbose=True, loc=False).update()
+ * (efa_xray/assimilation/ensrf.py:28-33,151).  This library sits exactly
+ * between `format_prior_state` (assimilation.py:120-154) and
+ * `format_posterior_state` (assimilation.py:157-171): it replaces the
+ * per-observation loop ensrf.py:50-149.  The Python host
+ * (efa_xray_amd.assimilation.ensrf.EnSRF) binds these symbols with ctypes;
+ * INTEGRATION.md shows the stub a reference maintainer would add.
+ *
+ * Conventions.
+ *  - extern "C", plain pointers and sizes.  `double` is IEEE binary64.
+ *  - Matrices are row-major with the ensemble member as the fastest axis:
+ *    `Xp[row * M + mem]` -- the layout of `EnsembleState.to_vect()`
+ *    (efa_xray/state/ensemble.py:110-114).
+ *  - Pointers named *_dev are device (HBM) addresses on the context's GPU;
+ *    every other pointer is host memory.  Per-observation arrays (length P)
+ *    are always host memory.
+ *  - The caller owns every buffer.  The library never frees or retains a
+ *    caller pointer after the call returns.
+ *  - Every function returns 0 on success and a negative efa_status on
+ *    failure; efa_last_error() returns a thread-local message.  No C++
+ *    exception crosses the ABI.
+ *  - One context per GPU.  Calls on one context must be serialised by the
+ *    caller.  All work is issued on the context's stream; functions that
+ *    return results to host memory synchronise that stream before returning.
+ *  - There is NO CPU fallback: without a usable gfx950 device
+ *    efa_ctx_create() fails with EFA_ERR_NO_DEVICE.
+ */
+#ifndef EFA_HIP_H
+#define EFA_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define EFA_ABI_VERSION 1
+
+typedef enum efa_status {
+  EFA_OK = 0,
+  EFA_ERR_INVALID = -1,    /* bad argument (shape, NULL pointer, option) */
+  EFA_ERR_NO_DEVICE = -2,  /* no HIP device / wrong architecture */
+  EFA_ERR_HIP = -3,        /* a HIP runtime call failed */
+  EFA_ERR_UNSUPPORTED = -4 /* valid request this build cannot serve */
+} efa_status;
+
+/* localisation modes: `loc` of EnSRF (ensrf.py:28,99) */
+#define EFA_LOC_NONE 0 /* loc in (None, False) */
+#define EFA_LOC_GC 1   /* loc == 'GC': Gaspari-Cohn, observation.py:117-130 */
+
+/* how the state sweep (Phase B) is executed; results agree to ~1e-14 */
+#define EFA_PATH_AUTO 0      /* transform when unlocalised and worth it */
+#define EFA_PATH_SWEEP 1     /* per-batch fused covariance/gain/update sweep */
+#define EFA_PATH_TRANSFORM 2 /* one pass: Xap = Xbp*T, xam = xbm + Xbp*w */
+
+typedef struct efa_ctx efa_ctx;
+
+/* ---- library / context --------------------------------------------------*/
+int efa_abi_version(void);
+const char *efa_last_error(void);
+/* number of visible HIP devices (0 without a GPU; never fails the process) */
+int efa_device_count(int *count);
+/* create a context on HIP device `device_id` (must be gfx950) */
+int efa_ctx_create(int device_id, efa_ctx **out);
+int efa_ctx_destroy(efa_ctx *ctx);
+/* issue all work on the caller's hipStream_t (e.g. torch's current stream);
+ * NULL restores the context's own stream */
+int efa_ctx_set_stream(efa_ctx *ctx, void *hip_stream);
+/* options: "obs_batch" (obs fused per sweep launch, 1..64, default 32),
+ *          "path" (EFA_PATH_*), "threads_hint" (ignored) */
+int efa_ctx_set_option(efa_ctx *ctx, const char *key, long value);
+int efa_ctx_get_option(efa_ctx *ctx, const char *key, long *value);
+int efa_ctx_synchronize(efa_ctx *ctx);
+
+/* ---- device memory for callers without their own allocator -------------*/
+int efa_malloc(efa_ctx *ctx, size_t bytes, void **dev_out);
+int efa_free(efa_ctx *ctx, void *dev);
+int efa_memcpy_h2d(efa_ctx *ctx, void *dst_dev, const void *src, size_t bytes);
+int efa_memcpy_d2h(efa_ctx *ctx, void *dst, const void *src_dev, size_t bytes);
+int efa_memcpy_d2d(efa_ctx *ctx, void *dst_dev, const void *src_dev, size_t bytes);
+
+/* ---- a3: mean-removed perturbation matrix --------------------------------
+ * Replaces `xbm = prior.mean(axis=1); Xbp = prior - xbm[:,None]`
+ * (assimilation.py:146-147) for `rows` rows of M members.  Also used for the
+ * obs-space priors of compute_ob_priors (assimilation.py:46-48).
+ * `scale` multiplies the perturbations (constant inflation,
+ * assimilation.py:62-68); pass 1.0 for none.  X_dev may equal Xp_dev. */
+int efa_form_perts_dev(efa_ctx *ctx, long rows, int M, const double *X_dev,
+                       double scale, double *xm_dev, double *Xp_dev);
+
+/* ---- a15: posterior member values ----------------------------------------
+ * Replaces `post = (xam[:,None] + Xap)[:Nstate]` (assimilation.py:168).
+ * post_dev may equal Xp_dev. */
+int efa_posterior_dev(efa_ctx *ctx, long rows, int M, const double *xm_dev,
+                      const double *Xp_dev, double *post_dev);
+
+/* ---- f1 (linear part): forward operator as a sparse row stencil ---------
+ * HX[k,:] = sum_j wts[k*npt+j] * X[idx[k*npt+j] - row_offset, :] over the
+ * stencil points owned by this shard (row_offset <= idx < row_offset+rows);
+ * points owned elsewhere contribute 0 so that a sum all-reduce across shards
+ * gives the full estimate (the payload of the multi-GPU exchange).
+ * Stands in for Observation.estimate -> EnsembleState.interpolate
+ * (observation.py:40-50, ensemble.py:170-239) once the stencil is known.
+ * idx/wts are host arrays of length P*npt. */
+int efa_forward_stencil_dev(efa_ctx *ctx, long rows, long row_offset, int M,
+                            const double *X_dev, long P, int npt,
+                            const int64_t *idx, const double *wts,
+                            double *HX_dev);
+
+/* ---- a5-a14: the serial EnSRF loop, data resident in HBM -----------------
+ * Replaces ensrf.py:50-149 for all P observations.
+ *
+ * State block (this GPU's shard):  xm_dev[rows], Xp_dev[rows*M], in/out.
+ *   Row i of the shard is state element (lead, col) with
+ *   i = lead*ncol + col, lead in [0,n_lead), col in [0,ncol): n_lead =
+ *   nvar*ntimes, ncol = the shard's (y,x) columns -- the order of to_vect().
+ *   With EFA_LOC_NONE pass n_lead=1, ncol=rows.
+ * Obs block (replicated on every shard): ym_dev[P], Yp_dev[P*M], in/out:
+ *   the obs-space prior means/perturbations that the reference appends to
+ *   the state (assimilation.py:149-150); on return they hold the reference's
+ *   final values of those augmented rows.
+ * Per observation k (host arrays, length P):
+ *   ob_value, ob_error (error VARIANCE, ensrf.py:79,91), ob_assim (0/1:
+ *   Observation.assimilate_this, ensrf.py:74), and for EFA_LOC_GC ob_lat,
+ *   ob_lon (degrees) and ob_halfwidth_km (Observation.localize_radius).
+ * Grid (host arrays, length ncol, degrees; EFA_LOC_GC only): lat/lon of each
+ *   local column (ensemble.py:254-267 distance_to_point).
+ * Diagnostics (host arrays, length P; written for every ob as the reference
+ *   does, ensrf.py:66,70,75,146-149): prior_mean, prior_var for all obs;
+ *   post_mean, post_var only where assimilated[k]==1 (left untouched
+ *   otherwise).
+ */
+int efa_ensrf_update_dev(efa_ctx *ctx, long rows, int M, long P,
+                         double *xm_dev, double *Xp_dev,
+                         double *ym_dev, double *Yp_dev,
+                         const double *ob_value, const double *ob_error,
+                         const uint8_t *ob_assim, int loc_mode,
+                         const double *ob_lat, const double *ob_lon,
+                         const double *ob_halfwidth_km,
+                         const double *grid_lat, const double *grid_lon,
+                         long ncol, long n_lead,
+                         double *prior_mean, double *prior_var,
+                         double *post_mean, double *post_var,
+                         uint8_t *assimilated);
+
+/* The two phases of efa_ensrf_update_dev, separately callable.
+ * Phase A (obs space, serial in k, identical on every shard): consumes the
+ * obs block, records the trajectory the state sweep needs and returns the
+ * diagnostics.  Phase B (state space): applies the recorded trajectory to
+ * `rows` state rows; independent per row, so shards never communicate.
+ * efa_obs_phase_dev must precede efa_state_phase_dev on the same context. */
+int efa_obs_phase_dev(efa_ctx *ctx, int M, long P, double *ym_dev,
+                      double *Yp_dev, const double *ob_value,
+                      const double *ob_error, const uint8_t *ob_assim,
+                      int loc_mode, const double *ob_lat, const double *ob_lon,
+                      const double *ob_halfwidth_km, double *prior_mean,
+                      double *prior_var, double *post_mean, double *post_var,
+                      uint8_t *assimilated);
+/* out-of-place allowed: (xm_in, Xp_in) -> (xm_out, Xp_out); pass the same
+ * pointers for in-place. */
+int efa_state_phase_dev(efa_ctx *ctx, long rows, int M, const double *xm_in_dev,
+                        const double *Xp_in_dev, double *xm_out_dev,
+                        double *Xp_out_dev, const double *grid_lat,
+                        const double *grid_lon, long ncol, long n_lead);
+
+/* ---- a3+a5-a15 fused for resident full-member states ---------------------
+ * prior members X_dev[rows*M] -> posterior members post_dev[rows*M] using the
+ * trajectory recorded by efa_obs_phase_dev.  Equivalent to
+ * efa_form_perts_dev + efa_state_phase_dev + efa_posterior_dev with one read
+ * and one write of the state when the transform path applies.
+ * post_dev may equal X_dev. */
+int efa_state_cycle_dev(efa_ctx *ctx, long rows, int M, const double *X_dev,
+                        double *post_dev, const double *grid_lat,
+                        const double *grid_lon, long ncol, long n_lead);
+
+/* ---- host-memory convenience: the augmented arrays of the reference ------
+ * xbm[A], Xbp[A*M] (A = N + P) exactly as format_prior_state returns them
+ * (assimilation.py:154), updated in place to the (xam, Xap) handed to
+ * format_posterior_state (ensrf.py:151).  Copies to the GPU, runs
+ * efa_ensrf_update_dev, copies back.  grid_lat/grid_lon have ncol entries,
+ * N = n_lead*ncol. */
+int efa_ensrf_update(efa_ctx *ctx, long A, long N, int M, long P, double *xbm,
+                     double *Xbp, const double *ob_value,
+                     const double *ob_error, const uint8_t *ob_assim,
+                     int loc_mode, const double *ob_lat, const double *ob_lon,
+                     const double *ob_halfwidth_km, const double *grid_lat,
+                     const double *grid_lon, long ncol, long n_lead,
+                     double *prior_mean, double *prior_var, double *post_mean,
+                     double *post_var, uint8_t *assimilated);
+
+/* ---- measurement support --------------------------------------------------
+ * Device time (ms) spent in the state-sweep kernels and in the obs-space
+ * kernels during the most recent efa_ensrf_update_dev / efa_obs_phase_dev /
+ * efa_state_phase_dev / efa_state_cycle_dev call, measured with HIP events on
+ * the context's stream, plus the number of state-sweep launches and the path
+ * taken (EFA_PATH_SWEEP / EFA_PATH_TRANSFORM).  Timing is off by default;
+ * enable with efa_ctx_set_option(ctx, "timing", 1). */
+int efa_last_timing(efa_ctx *ctx, double *state_ms, double *obs_ms,
+                    long *state_launches, int *path_taken);
+
+/* Fill rows of a resident state with the bench's synthetic ensemble
+ * (SURVEY.md 8d): X[i,m] = mu_i + sigma*z_im with counter-based normal
+ * deviates keyed by (seed, global row, member), so any sharding of the rows
+ * produces identical data. */
+int efa_fill_synthetic_dev(efa_ctx *ctx, long rows, long row_offset, int M,
+                           uint64_t seed, double sigma, double *X_dev);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* EFA_HIP_H */

@@ -1,0 +1,151 @@
+"""CPU-side tests (no GPU needed): the C-ABI library loads and exports every
+symbol include/efa_hip.h declares, the product never touches the oracle, and
+the host-side containers behave like the reference's."""
+import ctypes
+import os
+import re
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+from conftest import ROOT, load_golden
+from oracle import ensrf_oracle as orc
+
+
+def _declared_symbols():
+    text = open(os.path.join(ROOT, "include", "efa_hip.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(efa_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_library_builds_loads_and_exports_every_declared_symbol():
+    from efa_xray_amd import _lib
+    lib = _lib.load_library()
+    declared = _declared_symbols()
+    assert len(declared) >= 20
+    for name in declared:
+        assert hasattr(lib, name), "libefa_hip.so does not export %s" % name
+    # the ctypes table covers exactly the header
+    assert sorted(_lib.SIGNATURES.keys()) == declared
+    assert lib.efa_abi_version() == 1
+    out = subprocess.check_output(["nm", "-D", "--defined-only", _lib.LIB_PATH]).decode()
+    exported = set(re.findall(r" T (efa_[a-z0-9_]+)", out))
+    assert exported == set(declared)
+
+
+def test_no_cpu_fallback_without_gpu():
+    """Without a usable device the product fails loudly instead of computing on the CPU."""
+    from efa_xray_amd import _lib, EnSRF, EnsembleState, Observation
+    if _lib.device_count() > 0:
+        pytest.skip("a GPU is visible")
+    with pytest.raises(_lib.EfaError) as ei:
+        _lib.Context(0)
+    assert ei.value.status == _lib.EFA_ERR_NO_DEVICE
+    st = EnsembleState.from_array(np.random.default_rng(0).standard_normal((1, 1, 2, 3, 4)),
+                                  np.zeros((2, 3)), np.zeros((2, 3)))
+    ob = Observation(value=1.0, error=1.0, lat=0.0, lon=0.0, assimilate_this=True)
+    ob.estimate = lambda s: s.to_vect()[0]
+    with pytest.raises(_lib.EfaError):
+        EnSRF(st, [ob], verbose=False).update()
+
+
+def test_missing_library_fails_loudly(tmp_path):
+    from efa_xray_amd import _lib
+    with pytest.raises(RuntimeError, match="not built"):
+        _lib.load_library(str(tmp_path / "libefa_hip.so"))
+
+
+def test_product_never_imports_the_oracle():
+    bad = []
+    for base, _, files in os.walk(os.path.join(ROOT, "efa_xray_amd")):
+        for f in files:
+            if f.endswith((".py", ".hip", ".h", ".cpp")):
+                src = open(os.path.join(base, f)).read()
+                if re.search(r"^\s*(from|import)\s+oracle\b|oracle/", src, flags=re.M):
+                    bad.append(os.path.join(base, f))
+    assert not bad, bad
+    code = ("import sys; sys.path.insert(0, %r); import efa_xray_amd, efa_xray_amd._lib; "
+            "assert not any(m == 'oracle' or m.startswith('oracle.') for m in sys.modules)" % ROOT)
+    subprocess.check_call([sys.executable, "-c", code])
+
+
+# ---------------------------------------------------------------------------
+def _state(seed=0, shape=(2, 3, 4, 5, 6)):
+    from efa_xray_amd import EnsembleState
+    rng = np.random.default_rng(seed)
+    nvar, nt, ny, nx, nm = shape
+    lat, lon = np.meshgrid(np.linspace(30, 50, ny), np.linspace(230, 260, nx), indexing="ij")
+    arr = rng.standard_normal(shape)
+    vd = dict(("v%d" % i, (("validtime", "y", "x", "mem"), arr[i])) for i in range(nvar))
+    cd = dict(validtime=np.arange(nt) * 3600.0, lat=(("y", "x"), lat), lon=(("y", "x"), lon),
+              mem=np.arange(1, nm + 1))
+    return EnsembleState.from_vardict(vd, cd), arr, lat, lon
+
+
+def test_ensemble_state_surface_matches_reference_semantics():
+    st, arr, lat, lon = _state()
+    nvar, nt, ny, nx, nm = arr.shape
+    assert (st.nvars(), st.ntimes(), st.ny(), st.nx(), st.nmems()) == (nvar, nt, ny, nx, nm)
+    assert st.nstate() == nvar * nt * ny * nx
+    assert st.shape() == arr.shape
+    assert st.vars() == ["v0", "v1"]
+    v = st.to_vect()
+    # state-vector order: variable, time, y, x; member last (ensemble.py:110-114)
+    assert v.shape == (st.nstate(), nm) and np.array_equal(v, arr.reshape(-1, nm))
+    st2 = __import__("copy").deepcopy(st)
+    st2.from_vect(v * 2.0)
+    assert np.array_equal(st2.to_vect(), v * 2.0) and np.array_equal(st.to_vect(), v)
+    assert np.array_equal(st["lat"].values, lat) and st["lon"].shape == lon.shape
+    # dims given in another order are transposed to (validtime, y, x, mem)
+    from efa_xray_amd import EnsembleState
+    st3 = EnsembleState.from_vardict({"a": (("mem", "x", "y", "validtime"), np.transpose(arr[0], (3, 2, 1, 0)))},
+                                     dict(lat=lat, lon=lon))
+    assert np.array_equal(st3.to_vect(), arr[0].reshape(-1, nm))
+    pert = st.ensemble_perts()
+    assert np.allclose(pert.to_vect().mean(axis=1), 0.0, atol=1e-15)
+    assert np.allclose(st.ensemble_mean()["v1"], arr[1].mean(axis=-1))
+
+
+def test_geometry_helpers_match_reference_known_answers():
+    from efa_xray_amd import EnsembleState, Observation, gaspari_cohn, haversine
+    k = load_golden("KAT")
+    assert np.array_equal(gaspari_cohn(k["gc_d"], float(k["gc_c"])), k["gc_w"])
+    hv = np.array([haversine(tuple(a), tuple(b)) for a, b in zip(k["hv_a"], k["hv_b"])])
+    assert np.array_equal(hv, k["hv_km"])
+    st = EnsembleState.from_array(np.zeros((1, 1, 9, 12, 2)), k["dp_lat"], k["dp_lon"])
+    assert np.array_equal(st.distance_to_point(*k["dp_pt"]), k["dp_km"])
+    ob = Observation(lat=k["dp_pt"][0], lon=k["dp_pt"][1], localize_radius=900.0)
+    w = ob.localize(st)
+    assert np.array_equal(w, orc.localize_state(k["dp_lat"], k["dp_lon"], k["dp_pt"][0], k["dp_pt"][1], 900.0))
+    obs = [Observation(lat=a[0], lon=a[1]) for a in k["hv_a"][:8]]
+    w2 = ob.localize(obs)
+    assert np.array_equal(w2, orc.localize_obs(k["hv_a"][:8, 0], k["hv_a"][:8, 1], ob.lat, ob.lon, 900.0))
+    # 1-D lat/lon columns broadcast over y
+    st1 = EnsembleState.from_array(np.zeros((1, 1, 3, 4, 2)), np.arange(4.0), np.arange(4.0) * 2)
+    cl, co = st1.column_latlon()
+    assert np.array_equal(cl, np.tile(np.arange(4.0), 3)) and np.array_equal(co, np.tile(np.arange(4.0) * 2, 3))
+
+
+def test_observation_defaults_and_interpolate_stencil():
+    from efa_xray_amd import Observation
+    ob = Observation()
+    assert ob.assimilate_this is False and ob.assimilated is False and ob.localize_radius is None
+    st, arr, lat, lon = _state(3)
+    o = Observation(value=1.0, obtype="v1", time=4000.0, lat=41.3, lon=244.4, error=1.0)
+    ye = o.estimate(st)
+    rows, wts = o.stencil(st)
+    assert ye.shape == (st.nmems(),)
+    assert np.allclose(ye, (wts[:, None] * st.to_vect()[rows]).sum(axis=0))
+    iy, ix, sw = orc.interp_space_weights(lat, lon, 41.3, 244.4)
+    assert abs(wts.sum() - 1.0) < 1e-12 and abs(sw.sum() - 1.0) < 1e-12
+    # time weights as coded in the reference (ensemble.py:218-224): weight of the
+    # later time = |t - t_later| / dt
+    w_later = abs(4000.0 - 7200.0) / 3600.0
+    nt, ny, nx = st.ntimes(), st.ny(), st.nx()
+    later = [(1 * nt + 2) * ny * nx + y * nx + x for y, x in zip(iy, ix)]
+    got = dict(zip(rows.tolist(), wts.tolist()))
+    assert np.allclose([got[r] for r in later], w_later * sw)
+    assert o.estimate(st) is not None
+    assert Observation(obtype="v0", time=1e9, lat=40, lon=240).estimate(st) is None

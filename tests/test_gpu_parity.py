@@ -1,0 +1,409 @@
+"""GPU parity tests: the HIP path (through the C ABI) against the reference's
+golden vectors and against the CPU oracle on seeded inputs.
+
+Tolerance (BASELINE.json north_star / SURVEY.md 8d): float64,
+max|hip - ref| <= 1e-10 * max|ref| per array and elementwise rtol 1e-10 with
+atol 1e-12*max|ref|.
+"""
+import numpy as np
+import pytest
+
+from conftest import load_golden, GOLDEN_CASES
+from oracle import ensrf_oracle as orc
+
+pytestmark = pytest.mark.gpu
+
+RTOL = 1e-10
+
+
+def _ctx():
+    from efa_xray_amd import _lib
+    return _lib.get_context(0)
+
+
+def assert_parity(got, ref, what):
+    got = np.asarray(got, dtype=np.float64)
+    ref = np.asarray(ref, dtype=np.float64)
+    assert got.shape == ref.shape, what
+    if ref.size == 0:
+        return
+    scale = np.nanmax(np.abs(ref))
+    assert np.array_equal(np.isnan(got), np.isnan(ref)), what + ": NaN pattern"
+    err = np.nanmax(np.abs(got - ref)) if np.isfinite(scale) else 0.0
+    assert err <= RTOL * max(scale, 1e-300), "%s: max abs err %.3e vs scale %.3e" % (what, err, scale)
+    np.testing.assert_allclose(got, ref, rtol=RTOL, atol=1e-12 * max(scale, 1e-300), equal_nan=True,
+                               err_msg=what)
+
+
+def golden_kwargs(g):
+    nvar, nt, ny, nx, M = [int(v) for v in g["shape"]]
+    kw = dict(loc_mode=0)
+    if g["loc"] == "GC":
+        glat, glon = g["grid_lat"], g["grid_lon"]
+        if glat.ndim == 1:
+            glat, glon = np.tile(glat, ny), np.tile(glon, ny)
+        kw = dict(loc_mode=1, ob_lat=g["ob_lat"], ob_lon=g["ob_lon"], ob_halfwidth=g["ob_radius"],
+                  grid_lat=glat.reshape(-1), grid_lon=glon.reshape(-1), n_lead=nvar * nt)
+    return kw
+
+
+def oracle_kwargs(g):
+    nvar, nt, ny, nx, M = [int(v) for v in g["shape"]]
+    if g["loc"] != "GC":
+        return {}
+    return dict(loc="GC", ob_lat=g["ob_lat"], ob_lon=g["ob_lon"], ob_halfwidth=g["ob_radius"],
+                grid_lat=g["grid_lat"], grid_lon=g["grid_lon"], state_shape=(nvar, nt, ny, nx))
+
+
+def prior_arrays(g):
+    nvar, nt, ny, nx, M = [int(v) for v in g["shape"]]
+    N = nvar * nt * ny * nx
+    if "xbm" in g:
+        return N, g["xbm"].copy(), g["Xbp"].copy()
+    xbm, Xbp = orc.format_prior_state(g["X"].reshape(N, M), g["HX"])
+    return N, xbm, Xbp
+
+
+@pytest.mark.parametrize("name", GOLDEN_CASES)
+@pytest.mark.parametrize("path,batch", [("sweep", 32), ("sweep", 1), ("sweep", 7), ("sweep", 64),
+                                        ("auto", 32), ("transform", 16)])
+def test_host_abi_matches_reference_goldens(name, path, batch):
+    """efa_ensrf_update on the reference's augmented arrays == the reference's (xam, Xap)."""
+    from efa_xray_amd import _lib
+    g = load_golden(name)
+    N, xbm, Xbp = prior_arrays(g)
+    ctx = _ctx()
+    ctx.set_option("obs_batch", batch)
+    ctx.set_option("path", {"auto": 0, "sweep": 1, "transform": 2}[path])
+    diag = ctx.ensrf_update_host(xbm, Xbp, N, g["ob_value"], g["ob_error"], g["ob_assim"], **golden_kwargs(g))
+    ctx.set_option("path", 0)
+    ctx.set_option("obs_batch", 32)
+    assert_parity(xbm, g["xam"], name + " xam")
+    if "Xap" in g:
+        assert_parity(Xbp, g["Xap"], name + " Xap")
+    post = orc.format_posterior_state(xbm, Xbp, N)
+    assert_parity(post, g["post"], name + " post")
+    for key in ("prior_mean", "prior_var", "post_mean", "post_var"):
+        assert_parity(diag[key], g[key], name + " " + key)
+    assert np.array_equal(diag["assimilated"], g["assimilated"])
+
+
+class _StencilOb(object):
+    pass
+
+
+def _make_api_objects(g):
+    from efa_xray_amd import EnsembleState, Observation
+
+    class StencilOb(Observation):
+        def estimate(self, state):
+            rows = state.to_vect()[self.idx]
+            if len(self.idx) == 1 and self.wts[0] == 1.0:
+                return rows[0].copy()
+            return (self.wts[:, None] * rows).sum(axis=0)
+
+    state = EnsembleState.from_array(g["X"], g["grid_lat"], g["grid_lon"])
+    obs = []
+    for k in range(len(g["ob_value"])):
+        nz = g["sten_wts"][k] != 0
+        ob = StencilOb(value=float(g["ob_value"][k]), error=float(g["ob_error"][k]),
+                       lat=float(g["ob_lat"][k]), lon=float(g["ob_lon"][k]),
+                       assimilate_this=bool(g["ob_assim"][k]),
+                       localize_radius=(None if np.isnan(g["ob_radius"][k]) else float(g["ob_radius"][k])))
+        ob.idx = g["sten_idx"][k][nz]
+        ob.wts = g["sten_wts"][k][nz]
+        obs.append(ob)
+    return state, obs
+
+
+@pytest.mark.parametrize("name", GOLDEN_CASES)
+def test_python_api_matches_reference_goldens(name):
+    """EnSRF(state, obs, loc=...).update() == the reference's update() outputs."""
+    from efa_xray_amd import EnSRF
+    g = load_golden(name)
+    state, obs = _make_api_objects(g)
+    X_before = state.to_vect().copy()
+    post_state, obs_out = EnSRF(state, obs, verbose=False, loc=(g["loc"] or False)).update()
+    assert obs_out is obs
+    assert post_state is not state
+    assert np.array_equal(state.to_vect(), X_before), "prior must not be modified"
+    assert_parity(post_state.to_vect(), g["post"], name + " post")
+    for key in ("prior_mean", "prior_var"):
+        assert_parity([getattr(o, key) for o in obs], g[key], name + " " + key)
+    for k, o in enumerate(obs):
+        assert bool(o.assimilated) == bool(g["assimilated"][k])
+        if o.assimilated:
+            assert abs(o.post_mean - g["post_mean"][k]) <= RTOL * max(1.0, abs(g["post_mean"][k]))
+            assert abs(o.post_var - g["post_var"][k]) <= RTOL * max(1.0, abs(g["post_var"][k]))
+        else:
+            assert o.post_mean is None and o.post_var is None
+
+
+def test_format_prior_and_posterior_helpers():
+    from efa_xray_amd import EnSRF
+    g = load_golden("G2")
+    state, obs = _make_api_objects(g)
+    flt = EnSRF(state, obs, verbose=False, loc="GC")
+    xbm, Xbp = flt.format_prior_state()
+    assert_parity(xbm, g["xbm"], "xbm")
+    assert_parity(Xbp, g["Xbp"], "Xbp")
+    xam, Xap = flt.update_arrays(xbm, Xbp)
+    assert_parity(xam, g["xam"], "xam")
+    assert_parity(Xap, g["Xap"], "Xap")
+    post_state, _ = flt.format_posterior_state(xam, Xap)
+    assert_parity(post_state.to_vect(), g["post"], "post")
+
+
+# ---------------------------------------------------------------------------
+# seeded inputs vs the oracle: shapes the goldens do not cover
+# ---------------------------------------------------------------------------
+def _random_case(seed, N, M, P, loc, frac_assim=0.9, ncol=None):
+    rng = np.random.default_rng(seed)
+    X = rng.standard_normal((N, 1)) + 3.0 * rng.standard_normal((N, M))
+    rows = rng.choice(N, P, replace=(P > N))
+    HX = X[rows]
+    val = HX.mean(axis=1) + rng.standard_normal(P)
+    err = rng.uniform(0.5, 2.0, P)
+    asm = rng.random(P) < frac_assim
+    case = dict(X=X, HX=HX, val=val, err=err, asm=asm, N=N, M=M, P=P, loc=loc)
+    if loc:
+        ncol = ncol or N
+        assert N % ncol == 0
+        ny = int(np.sqrt(ncol))
+        while ncol % ny:
+            ny -= 1
+        nx = ncol // ny
+        lat, lon = np.meshgrid(np.linspace(-70, 70, ny), np.linspace(0, 357, nx), indexing="ij")
+        case.update(lat=lat, lon=lon, n_lead=N // ncol, ny=ny, nx=nx,
+                    ob_lat=lat.reshape(-1)[rows % ncol] + 0.2 * rng.standard_normal(P),
+                    ob_lon=lon.reshape(-1)[rows % ncol] + 0.2 * rng.standard_normal(P),
+                    hw=rng.uniform(800, 4000, P))
+    return case
+
+
+def _run_oracle(c):
+    kw = {}
+    if c["loc"]:
+        kw = dict(loc="GC", ob_lat=c["ob_lat"], ob_lon=c["ob_lon"], ob_halfwidth=c["hw"], grid_lat=c["lat"],
+                  grid_lon=c["lon"], state_shape=(c["n_lead"], 1, c["ny"], c["nx"]))
+    xbm, Xbp = orc.format_prior_state(c["X"], c["HX"])
+    xam, Xap, diag = orc.ensrf_update(xbm, Xbp, c["N"], c["val"], c["err"], c["asm"], **kw)
+    return xam, Xap, diag
+
+
+def _run_hip(c, path="auto", batch=32):
+    ctx = _ctx()
+    ctx.set_option("obs_batch", batch)
+    ctx.set_option("path", {"auto": 0, "sweep": 1, "transform": 2}[path])
+    xbm, Xbp = orc.format_prior_state(c["X"], c["HX"])
+    kw = dict(loc_mode=0)
+    if c["loc"]:
+        kw = dict(loc_mode=1, ob_lat=c["ob_lat"], ob_lon=c["ob_lon"], ob_halfwidth=c["hw"],
+                  grid_lat=c["lat"].reshape(-1), grid_lon=c["lon"].reshape(-1), n_lead=c["n_lead"])
+    diag = ctx.ensrf_update_host(xbm, Xbp, c["N"], c["val"], c["err"], c["asm"], **kw)
+    ctx.set_option("path", 0)
+    ctx.set_option("obs_batch", 32)
+    return xbm, Xbp, diag
+
+
+SHAPES = [
+    # N, M, P, loc
+    (1, 2, 1, False), (5, 2, 3, False), (63, 3, 9, False), (65, 7, 70, False),
+    (1000, 21, 33, False), (257, 100, 150, False), (4096, 50, 64, False), (300, 128, 140, False),
+    (513, 130, 20, False), (200, 200, 12, False), (129, 256, 5, False),
+    (48, 6, 10, True), (1024, 20, 90, True), (2304, 80, 130, True), (900, 33, 40, True),
+]
+
+
+@pytest.mark.parametrize("N,M,P,loc", SHAPES)
+def test_seeded_shapes_vs_oracle(N, M, P, loc):
+    c = _random_case(100 + N + M + P, N, M, P, loc, ncol=(N // 4 if loc and N % 4 == 0 and N >= 1024 else None))
+    xam, Xap, diag = _run_oracle(c)
+    for path in (("sweep", "auto") if not loc else ("sweep",)):
+        h_xam, h_Xap, h_diag = _run_hip(c, path=path)
+        assert_parity(h_xam, xam, "xam %s" % path)
+        assert_parity(h_Xap, Xap, "Xap %s" % path)
+        for key in ("prior_mean", "prior_var", "post_mean", "post_var"):
+            assert_parity(h_diag[key], diag[key], key)
+        assert np.array_equal(h_diag["assimilated"], diag["assimilated"])
+
+
+def test_edge_cases_no_obs_and_none_assimilated():
+    c = _random_case(5, 300, 20, 12, False, frac_assim=0.0)
+    xbm, Xbp = orc.format_prior_state(c["X"], c["HX"])
+    h_xam, h_Xap, h_diag = _run_hip(c)
+    assert np.array_equal(h_xam, xbm) and np.array_equal(h_Xap, Xbp)   # untouched, bit for bit
+    assert not h_diag["assimilated"].any()
+    assert np.all(np.isnan(h_diag["post_mean"]))
+    assert_parity(h_diag["prior_var"], np.var(Xbp[300:], axis=1), "prior_var")
+    # P = 0
+    ctx = _ctx()
+    x0, X0 = xbm[:300].copy(), Xbp[:300].copy()
+    d = ctx.ensrf_update_host(x0, X0, 300, np.zeros(0), np.zeros(0), np.zeros(0, dtype=bool))
+    assert np.array_equal(x0, xbm[:300]) and np.array_equal(X0, Xbp[:300])
+    assert d["prior_mean"].shape == (0,)
+
+
+def test_unassimilated_obs_leave_state_untouched_and_zero_taper_rows_bit_unchanged():
+    # F3: rows whose taper is 0 for every ob are returned bit-identical
+    c = _random_case(9, 4096, 40, 30, True, ncol=1024)
+    c["hw"][:] = 150.0                       # tiny footprints: most rows outside 2*halfwidth
+    xbm, Xbp = orc.format_prior_state(c["X"], c["HX"])
+    h_xam, h_Xap, _ = _run_hip(c, path="sweep")
+    w = np.zeros(1024, dtype=bool)
+    for k in range(c["P"]):
+        if c["asm"][k]:
+            w |= orc.localize_state(c["lat"], c["lon"], c["ob_lat"][k], c["ob_lon"][k], c["hw"][k]).reshape(-1) != 0
+    untouched = np.tile(~w, c["n_lead"])
+    assert untouched.sum() > 0
+    assert np.array_equal(h_Xap[:c["N"]][untouched], Xbp[:c["N"]][untouched])
+    assert np.array_equal(h_xam[:c["N"]][untouched], xbm[:c["N"]][untouched])
+    xam, Xap, _ = _run_oracle(c)
+    assert_parity(h_Xap, Xap, "Xap")
+
+
+def test_posterior_obs_variance_identity():
+    # for an ob whose own taper is 1: post_var = var*R/(var+R) (tier 3)
+    c = _random_case(21, 500, 30, 25, False, frac_assim=1.0)
+    _, _, d = _run_hip(c)
+    expect = d["prior_var"] * c["err"] / (d["prior_var"] + c["err"])
+    np.testing.assert_allclose(d["post_var"], expect, rtol=1e-9)
+
+
+def test_logical_shards_equal_unsharded_bit_for_bit():
+    """Row independence (F1): updating two column shards separately with the
+    replicated obs block gives exactly the bits of the unsharded update."""
+    c = _random_case(33, 3 * 800, 50, 70, True, ncol=800)
+    ctx = _ctx()
+    ctx.set_option("path", 1)
+    N, M, P, ncol, L = c["N"], c["M"], c["P"], 800, 3
+    xbm, Xbp = orc.format_prior_state(c["X"], c["HX"])
+    full_x, full_X, _ = _run_hip(c, path="sweep")
+    lat, lon = c["lat"].reshape(-1), c["lon"].reshape(-1)
+    out_x = np.empty(N)
+    out_X = np.empty((N, M))
+    for lo, hi in ((0, 333), (333, 800)):
+        cols = np.arange(lo, hi)
+        rows = (np.arange(L)[:, None] * ncol + cols[None, :]).reshape(-1)
+        xs = np.ascontiguousarray(np.hstack((xbm[rows], xbm[N:])))
+        Xs = np.ascontiguousarray(np.vstack((Xbp[rows], Xbp[N:])))
+        ctx.ensrf_update_host(xs, Xs, len(rows), c["val"], c["err"], c["asm"], loc_mode=1, ob_lat=c["ob_lat"],
+                              ob_lon=c["ob_lon"], ob_halfwidth=c["hw"], grid_lat=lat[lo:hi], grid_lon=lon[lo:hi],
+                              n_lead=L)
+        out_x[rows] = xs[:len(rows)]
+        out_X[rows] = Xs[:len(rows)]
+    ctx.set_option("path", 0)
+    assert np.array_equal(out_x, full_x[:N]) and np.array_equal(out_X, full_X[:N])
+
+
+def test_sweep_and_transform_paths_agree_at_scale():
+    """1e6 rows x 100 members x 400 obs: the two Phase-B paths agree to 1e-11
+    and an encode/decode style round trip (posterior of posterior-free obs) holds."""
+    from efa_xray_amd import _lib
+    ctx = _ctx()
+    rows, M, P = 1_000_000, 100, 400
+    rng = np.random.default_rng(4)
+    X = ctx.empty((rows, M))
+    ctx.fill_synthetic(rows, 0, M, 1234, 3.0, X)
+    pick = np.sort(rng.choice(rows, P, replace=False)).astype(np.int64)
+    HX = ctx.empty((P, M))
+    ctx.forward_stencil(rows, 0, M, X, pick[:, None], np.ones((P, 1)), HX)
+    hx = HX.download()
+    val = hx.mean(axis=1) + rng.standard_normal(P)
+    err = np.ones(P)
+    asm = np.ones(P, dtype=bool)
+    outs = {}
+    for path in (1, 2):
+        ctx.set_option("path", path)
+        ym = ctx.empty((P,))
+        Yp = ctx.to_device(hx)
+        ctx.form_perts(P, M, Yp, ym, Yp)
+        d = ctx.obs_phase(M, P, ym, Yp, val, err, asm)
+        post = ctx.empty((rows, M))
+        ctx.state_cycle(rows, M, X, post)
+        assert ctx.last_timing()["path"] == path
+        outs[path] = (post.download(), d)
+        post.free()
+    ctx.set_option("path", 0)
+    a, b = outs[1][0], outs[2][0]
+    scale = np.abs(a).max()
+    assert np.abs(a - b).max() <= 1e-11 * scale
+    # posterior at the observed rows reproduces the diagnostics' post_mean / post_var
+    d = outs[1][1]
+    sub = a[pick[-1]]
+    assert abs(sub.mean() - d["post_mean"][-1]) <= 1e-10 * max(1.0, abs(d["post_mean"][-1]))
+    assert abs(sub.var() - d["post_var"][-1]) <= 1e-9 * max(1.0, d["post_var"][-1])
+    # oracle on a thin slice of rows with the same obs trajectory
+    sl = np.concatenate([np.arange(0, 2000), pick])
+    Xs = X.download()[sl]
+    ref_post, _, _, rd = orc.ensrf_cycle(Xs, hx, val, err, asm)
+    assert_parity(a[sl], ref_post, "slice post vs oracle")
+    assert_parity(d["post_var"], rd["post_var"], "post_var")
+
+
+def test_helper_kernels_vs_oracle():
+    ctx = _ctx()
+    rng = np.random.default_rng(8)
+    for rows, M in ((1, 2), (77, 5), (1000, 50), (333, 100), (64, 256)):
+        X = rng.standard_normal((rows, M)) * 5 + rng.standard_normal((rows, 1))
+        d = ctx.to_device(X)
+        xm = ctx.empty((rows,))
+        Xp = ctx.empty((rows, M))
+        ctx.form_perts(rows, M, d, xm, Xp)
+        assert_parity(xm.download(), X.mean(axis=1), "mean")
+        assert_parity(Xp.download(), X - X.mean(axis=1)[:, None], "perts")
+        ctx.form_perts(rows, M, d, xm, Xp, scale=1.3)
+        assert_parity(Xp.download(), (X - X.mean(axis=1)[:, None]) * 1.3, "inflated perts")
+        post = ctx.empty((rows, M))
+        ctx.posterior(rows, M, xm, Xp, post)
+        assert_parity(post.download(), orc.inflate_constant(X, 1.3), "posterior/inflate")
+    # forward stencil incl. sharding by row ranges
+    rows, M, P = 500, 20, 40
+    X = rng.standard_normal((rows, M))
+    idx = rng.integers(0, rows, (P, 4))
+    wts = rng.random((P, 4))
+    wts /= wts.sum(axis=1, keepdims=True)
+    ref = np.array([(wts[k][:, None] * X[idx[k]]).sum(axis=0) for k in range(P)])
+    d = ctx.to_device(X)
+    HX = ctx.empty((P, M))
+    ctx.forward_stencil(rows, 0, M, d, idx, wts, HX)
+    assert_parity(HX.download(), ref, "stencil")
+    acc = np.zeros((P, M))
+    for lo, hi in ((0, 123), (123, 500)):
+        ds = ctx.to_device(X[lo:hi])
+        ctx.forward_stencil(hi - lo, lo, M, ds, idx, wts, HX)
+        acc += HX.download()
+    assert_parity(acc, ref, "sharded stencil sum")
+
+
+def test_synthetic_fill_is_shard_invariant_and_sane():
+    ctx = _ctx()
+    full = ctx.empty((4000, 30))
+    ctx.fill_synthetic(4000, 0, 30, 77, 3.0, full)
+    a = full.download()
+    part = ctx.empty((1500, 30))
+    ctx.fill_synthetic(1500, 2500, 30, 77, 3.0, part)
+    assert np.array_equal(part.download(), a[2500:])
+    z = (a - a.mean(axis=1, keepdims=True)) / 3.0
+    assert abs(z.std() - 1.0) < 0.05 and abs(a.mean()) < 0.1
+    assert np.isfinite(a).all()
+
+
+def test_errors_are_loud():
+    from efa_xray_amd import _lib, EnSRF, EnsembleState, Observation
+    ctx = _ctx()
+    with pytest.raises(_lib.EfaError):
+        ctx.set_option("obs_batch", 1000)
+    with pytest.raises(_lib.EfaError):
+        ctx.set_option("nonsense", 1)
+    x = np.zeros(4)
+    X = np.zeros((4, 1))
+    with pytest.raises(_lib.EfaError):     # M = 1: covariance divides by M-1
+        ctx.ensrf_update_host(x, X, 3, [0.0], [1.0], [True])
+    st = EnsembleState.from_array(np.zeros((1, 1, 2, 2, 4)), np.zeros((2, 2)), np.zeros((2, 2)))
+    ob = Observation(value=1.0, error=1.0, lat=0.0, lon=0.0, assimilate_this=True)
+    ob.estimate = lambda s: np.zeros(4)
+    with pytest.raises(ValueError):
+        EnSRF(st, [ob], verbose=False, loc=True).update()
+    with pytest.raises(ValueError):
+        EnSRF(st, [ob], verbose=False, loc='GC').update()   # localize_radius is None
