@@ -128,8 +128,8 @@ __global__ __launch_bounds__(kThreadsT) void k_transform(const TransformArgs p) 
       if ((s & 1) == 1) __builtin_amdgcn_sched_barrier(0);
     }
 
-    // acc[t][v] = D[row 4g+v][col 16t+n]
-    double dm[4];  // mean increment of rows 4g+v : column M of the product
+    // acc[t][v] = D[row 4v+g][col 16t+n]  (layout probed on gfx950: tools/mfma_probe.hip)
+    double dm[4];  // mean increment of rows 4v+g : column M of the product
 #pragma unroll
     for (int v = 0; v < 4; ++v) dm[v] = 0.0;
 #pragma unroll
@@ -142,9 +142,9 @@ __global__ __launch_bounds__(kThreadsT) void k_transform(const TransformArgs p) 
     double base[4];
 #pragma unroll
     for (int v = 0; v < 4; ++v) {
-      const long row = r0 + 4 * g + v;
+      const long row = r0 + 4 * v + g;
       double m0;
-      if (p.fused_members) m0 = __shfl(rmean, 4 * g + v, 64);
+      if (p.fused_members) m0 = __shfl(rmean, 4 * v + g, 64);
       else m0 = (row < p.nrows) ? p.xin[row] : 0.0;
       base[v] = m0 + dm[v];
     }
@@ -154,7 +154,7 @@ __global__ __launch_bounds__(kThreadsT) void k_transform(const TransformArgs p) 
       if (col < M) {
 #pragma unroll
         for (int v = 0; v < 4; ++v) {
-          const long row = r0 + 4 * g + v;
+          const long row = r0 + 4 * v + g;
           if (row < p.nrows) {
             const double val = p.fused_members ? (base[v] + acc[t][v]) : acc[t][v];
             p.Xout[(size_t)row * M + col] = val;
@@ -165,7 +165,7 @@ __global__ __launch_bounds__(kThreadsT) void k_transform(const TransformArgs p) 
     if (!p.fused_members && n == 0) {
 #pragma unroll
       for (int v = 0; v < 4; ++v) {
-        const long row = r0 + 4 * g + v;
+        const long row = r0 + 4 * v + g;
         if (row < p.nrows) p.xout[row] = base[v];
       }
     }

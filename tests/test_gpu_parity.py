@@ -263,11 +263,15 @@ def test_unassimilated_obs_leave_state_untouched_and_zero_taper_rows_bit_unchang
 
 
 def test_posterior_obs_variance_identity():
-    # for an ob whose own taper is 1: post_var = var*R/(var+R) (tier 3)
+    # closed form of the ob's own row: ye' = ye*(1 - beta*kmat) with the reference's mixed
+    # conventions (np.var is ddof=0, the covariance divides by M-1: ensrf.py:69,95,135)
     c = _random_case(21, 500, 30, 25, False, frac_assim=1.0)
     _, _, d = _run_hip(c)
-    expect = d["prior_var"] * c["err"] / (d["prior_var"] + c["err"])
-    np.testing.assert_allclose(d["post_var"], expect, rtol=1e-9)
+    M = c["M"]
+    var, R = d["prior_var"], c["err"]
+    kmat = (var * M / (M - 1)) / (var + R)
+    beta = 1.0 / (1.0 + np.sqrt(R / (var + R)))
+    np.testing.assert_allclose(d["post_var"], var * (1.0 - beta * kmat) ** 2, rtol=1e-9)
 
 
 def test_logical_shards_equal_unsharded_bit_for_bit():
