@@ -76,7 +76,7 @@ struct efa_ctx {
   int device = 0;
   hipStream_t own_stream = nullptr;
   hipStream_t stream = nullptr;
-  long obs_batch = 32;
+  long obs_batch = 64;
   long path = EFA_PATH_AUTO;
   long timing = 0;
 
@@ -121,13 +121,11 @@ long effective_batch(const efa_ctx* c, int M) {
   long b = c->obs_batch;
   if (b < 1) b = 1;
   if (b > kMaxBatch) b = kMaxBatch;
-  // keep the sweep's LDS image of the batch (ye rows + coefs) under 60 KiB
-  int nch = (M + 7) / 8;
-  if (nch > 16) nch = (nch <= 20) ? 20 : (nch <= 24) ? 24 : 32;
-  const long per_ob = (long)(8 * nch + kCoefStride) * (long)sizeof(double);
-  const long cap = (60L * 1024) / per_ob;
-  if (b > cap) b = cap;
-  if (b < 1) b = 1;
+  // LDS budgets: the sweep's image of the batch (ye rows + coefs, either lane layout) and the
+  // diag kernel's ring (ye rows + scalars + the GC taper matrix) must fit one CU's 160 KiB.
+  const long s4 = sweep_slots(M), s16 = 32L * ((M + 31) / 32);
+  const long per_ob = ((s4 > s16 ? s4 : s16) + kCoefStride) * (long)sizeof(double);
+  while (b > 1 && (b * per_ob > 150L * 1024 || (long)diag_lds_bytes((int)s4, (int)b, 1) > 150L * 1024)) --b;
   return b;
 }
 

@@ -80,6 +80,9 @@ struct TransformArgs {
   int fused_members;  // 1: Xin holds prior members, Xout receives posterior members
 };
 
+int sweep_slots(int M);                                  // padded row length of the quad layout
+size_t diag_lds_bytes(int slots, int nb, int loc_mode);  // dynamic LDS of the diag kernel
+
 hipError_t launch_sweep(const SweepArgs& a, hipStream_t s);
 hipError_t launch_diag(const DiagArgs& a, hipStream_t s);
 hipError_t launch_transform(const TransformArgs& a, hipStream_t s);

@@ -10,12 +10,15 @@
 // for every row of the (rows x M) block, all obs of the batch applied while
 // the row sits in registers: one HBM read + one write of the block per batch.
 //
-// Thread layout ("quad per row"): 4 consecutive lanes own one row; lane q of
-// the quad holds members {8c+2q, 8c+2q+1 : c = 0..NCH-1} so that every global
-// access is a 16-byte load and the 4 lanes of a quad cover 64 contiguous bytes.
-// A wave64 therefore streams 16 consecutive rows (contiguous in memory).  The
-// M-long dot product is 2*NCH FMAs per lane + a 2-step DPP butterfly over the
-// quad; no LDS traffic for the state, LDS only broadcasts the batch's ye rows.
+// Thread layout ("L lanes per row", L = 4 or 16): L consecutive lanes own one
+// row; lane j of the group holds members {2L*c+2j, 2L*c+2j+1 : c = 0..NC-1}, so
+// every global access is a 16-byte load and a group covers 32*L contiguous
+// bytes per chunk.  A wave64 streams 64/L consecutive rows (contiguous in
+// memory).  The M-long dot product is 2*NC FMAs per lane + a DPP butterfly over
+// the group; no LDS traffic for the state, LDS only broadcasts the batch's ye.
+//   L = 4 : fewest instructions per row -- the throughput layout (state rows).
+//   L = 16: shortest per-observation dependency chain -- the latency layout,
+//           used when there are too few rows to fill the chip (the obs block).
 #include "efa_device.h"
 #include "efa_internal.h"
 
@@ -24,13 +27,33 @@ namespace efa {
 namespace {
 
 constexpr int kThreads = 256;
-constexpr int kRowsPerBlock = kThreads / 4;  // 64
 
-template <int NCH, bool VEC>
-__device__ __forceinline__ void load_row(const double* __restrict__ p, int M, int q, double (&x)[2 * NCH]) {
+// ---- group reductions ------------------------------------------------------
+#define EFA_DPP_STEP(v, ctrl)                                                          \
+  do {                                                                                 \
+    int _lo = __double2loint(v), _hi = __double2hiint(v);                              \
+    _lo = __builtin_amdgcn_mov_dpp(_lo, (ctrl), 0xF, 0xF, true);                       \
+    _hi = __builtin_amdgcn_mov_dpp(_hi, (ctrl), 0xF, 0xF, true);                       \
+    v = v + __hiloint2double(_hi, _lo);                                                \
+  } while (0)
+
+template <int L>
+__device__ __forceinline__ double group_sum(double v) {
+  EFA_DPP_STEP(v, 0xB1);  // quad_perm [1,0,3,2]
+  EFA_DPP_STEP(v, 0x4E);  // quad_perm [2,3,0,1]
+  if (L == 16) {
+    EFA_DPP_STEP(v, 0x141);  // row_half_mirror: quads 0<->1, 2<->3
+    EFA_DPP_STEP(v, 0x140);  // row_mirror: the two halves of the 16-lane row
+  }
+  return v;
+}
+
+// ---- row <-> registers -------------------------------------------------------
+template <int L, int NC, bool VEC>
+__device__ __forceinline__ void load_row(const double* __restrict__ p, int M, int j, double (&x)[2 * NC]) {
 #pragma unroll
-  for (int c = 0; c < NCH; ++c) {
-    const int m0 = 8 * c + 2 * q;
+  for (int c = 0; c < NC; ++c) {
+    const int m0 = 2 * L * c + 2 * j;
     if (VEC) {
       if (m0 < M) {
         const double2 v = *reinterpret_cast<const double2*>(p + m0);
@@ -47,11 +70,11 @@ __device__ __forceinline__ void load_row(const double* __restrict__ p, int M, in
   }
 }
 
-template <int NCH, bool VEC>
-__device__ __forceinline__ void store_row(double* __restrict__ p, int M, int q, const double (&x)[2 * NCH]) {
+template <int L, int NC, bool VEC>
+__device__ __forceinline__ void store_row(double* __restrict__ p, int M, int j, const double (&x)[2 * NC]) {
 #pragma unroll
-  for (int c = 0; c < NCH; ++c) {
-    const int m0 = 8 * c + 2 * q;
+  for (int c = 0; c < NC; ++c) {
+    const int m0 = 2 * L * c + 2 * j;
     if (VEC) {
       if (m0 < M) *reinterpret_cast<double2*>(p + m0) = make_double2(x[2 * c], x[2 * c + 1]);
     } else {
@@ -61,54 +84,112 @@ __device__ __forceinline__ void store_row(double* __restrict__ p, int M, int q, 
   }
 }
 
-// dot(x, ye) over the lane's slots with two accumulators, then the quad total.
-template <int NCH>
-__device__ __forceinline__ double quad_dot(const double (&x)[2 * NCH], const double (&y)[2 * NCH]) {
-  double a0 = 0.0, a1 = 0.0;
+template <int L, int NC>
+__device__ __forceinline__ void lds_read_row(const double* __restrict__ ys, int j, double (&y)[2 * NC]) {
 #pragma unroll
-  for (int c = 0; c < NCH; ++c) {
-    a0 = __builtin_fma(x[2 * c], y[2 * c], a0);
-    a1 = __builtin_fma(x[2 * c + 1], y[2 * c + 1], a1);
+  for (int c = 0; c < NC; ++c) {
+    const double2 v = *reinterpret_cast<const double2*>(ys + 2 * L * c + 2 * j);
+    y[2 * c] = v.x;
+    y[2 * c + 1] = v.y;
   }
-  return quad_sum(a0 + a1);
+}
+
+// dot(x, ye) over the lane's slots with up to four independent FMA chains, then the group total
+template <int L, int NC>
+__device__ __forceinline__ double group_dot(const double (&x)[2 * NC], const double (&y)[2 * NC]) {
+  double s[4] = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+  for (int c = 0; c < 2 * NC; ++c) s[c & 3] = __builtin_fma(x[c], y[c], s[c & 3]);
+  return group_sum<L>((s[0] + s[1]) + (s[2] + s[3]));
+}
+
+// sum over the lane's valid slots of (x - mean)^2, then the group total
+template <int L, int NC>
+__device__ __forceinline__ double group_centered_sumsq(const double (&x)[2 * NC], double mean, int M, int j) {
+  double s[4] = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+  for (int c = 0; c < NC; ++c) {
+    const int m0 = 2 * L * c + 2 * j;
+    const double d0 = (m0 < M) ? (x[2 * c] - mean) : 0.0;
+    const double d1 = (m0 + 1 < M) ? (x[2 * c + 1] - mean) : 0.0;
+    s[(2 * c) & 3] = __builtin_fma(d0, d0, s[(2 * c) & 3]);
+    s[(2 * c + 1) & 3] = __builtin_fma(d1, d1, s[(2 * c + 1) & 3]);
+  }
+  return group_sum<L>((s[0] + s[1]) + (s[2] + s[3]));
+}
+
+// sum over ALL of the lane's slots of (x - mean)^2 (no masking), then the group total
+template <int L, int NC>
+__device__ __forceinline__ double group_sumsq_about(const double (&x)[2 * NC], double mean) {
+  double s[4] = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+  for (int c = 0; c < 2 * NC; ++c) {
+    const double d = x[c] - mean;
+    s[c & 3] = __builtin_fma(d, d, s[c & 3]);
+  }
+  return group_sum<L>((s[0] + s[1]) + (s[2] + s[3]));
+}
+
+template <int L, int NC>
+__device__ __forceinline__ double group_rowsum(const double (&x)[2 * NC]) {
+  double s[4] = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+  for (int c = 0; c < 2 * NC; ++c) s[c & 3] += x[c];
+  return group_sum<L>((s[0] + s[1]) + (s[2] + s[3]));
 }
 
 // ---------------------------------------------------------------------------
 // Sweep: rows x batch.
-// LDS: ye_s[nb][8*NCH] (zero padded) then coef_s[nb][4].
+// LDS: ye_s[nb][S] (zero padded, S = 2*L*NC) then coef_s[nb][4].
 // ---------------------------------------------------------------------------
-template <int NCH, bool VEC>
+template <int L, int NC, bool VEC>
 __global__ __launch_bounds__(kThreads) void k_sweep(const SweepArgs a) {
   extern __shared__ __align__(16) double smem[];
-  constexpr int S = 8 * NCH;
+  constexpr int S = 2 * L * NC;
+  constexpr int kRowsPerBlock = kThreads / L;
   double* ye_s = smem;
   double* coef_s = smem + (size_t)a.nb * S;
   const int tid = threadIdx.x;
   const int M = a.M;
 
-  for (int i = tid; i < a.nb * S; i += kThreads) {
-    const int k = i / S, m = i - k * S;
-    ye_s[i] = (m < M) ? a.Ye[(size_t)k * M + m] : 0.0;
+  if (VEC) {
+    // 16-byte copies, four in flight per thread (the batch image is small and latency-bound)
+    constexpr int S2 = S / 2;
+    const double2* src = reinterpret_cast<const double2*>(a.Ye);
+    double2* dst = reinterpret_cast<double2*>(ye_s);
+    const int M2 = M / 2;
+    const int total = a.nb * S2;
+#pragma unroll 4
+    for (int i = tid; i < total; i += kThreads) {
+      const int k = i / S2, m2 = i - k * S2;
+      dst[i] = (m2 < M2) ? src[(size_t)k * M2 + m2] : make_double2(0.0, 0.0);
+    }
+  } else {
+#pragma unroll 4
+    for (int i = tid; i < a.nb * S; i += kThreads) {
+      const int k = i / S, m = i - k * S;
+      ye_s[i] = (m < M) ? a.Ye[(size_t)k * M + m] : 0.0;
+    }
   }
   for (int i = tid; i < a.nb * kCoefStride; i += kThreads) coef_s[i] = a.coef[i];
   __syncthreads();
 
-  const int q = tid & 3;
-  const int r = tid >> 2;
+  const int j = tid & (L - 1);
+  const int r = tid / L;
   const double rM1 = 1.0 / (double)(M - 1);
   const long nblocks = (a.nrows + kRowsPerBlock - 1) / kRowsPerBlock;
 
   for (long blk = blockIdx.x; blk < nblocks; blk += gridDim.x) {
     const long row = blk * kRowsPerBlock + r;
     const bool live = (row < a.nrows) && !(row >= a.skip_lo && row < a.skip_hi);
-    double x[2 * NCH];
+    double x[2 * NC];
     double xm = 0.0;
     if (live) {
-      load_row<NCH, VEC>(a.Xin + (size_t)row * M, M, q, x);
+      load_row<L, NC, VEC>(a.Xin + (size_t)row * M, M, j, x);
       xm = a.xin[row];
     } else {
 #pragma unroll
-      for (int c = 0; c < 2 * NCH; ++c) x[c] = 0.0;
+      for (int c = 0; c < 2 * NC; ++c) x[c] = 0.0;
     }
     long col = 0;
     double rlat = 0.0, rlon = 0.0;
@@ -129,197 +210,230 @@ __global__ __launch_bounds__(kThreads) void k_sweep(const SweepArgs a) {
       } else if (a.taper_mode == kTaperObs) {
         if (obs_taper) w = gaspari_cohn(haversine_km(a.ob_lat[k], a.ob_lon[k], rlat, rlon), a.ob_hw[k]);
       }
-      double y[2 * NCH];
-      const double* yk = ye_s + k * S + 2 * q;
-#pragma unroll
-      for (int c = 0; c < NCH; ++c) {
-        const double2 v = *reinterpret_cast<const double2*>(yk + 8 * c);
-        y[2 * c] = v.x;
-        y[2 * c + 1] = v.y;
-      }
-      const double dot = quad_dot<NCH>(x, y);
+      double y[2 * NC];
+      lds_read_row<L, NC>(ye_s + k * S, j, y);
+      const double dot = group_dot<L, NC>(x, y);
       double kc = dot * rM1;   // kcov = dot/(Nens-1)
       kc = w * kc;             // localisation
       const double km = kc * ck[1];  // kmat = kcov/kdenom
       xm = xm + km * ck[0];    // xam = xbm + kmat*innov
       const double kb = ck[2] * km;  // beta*kmat
 #pragma unroll
-      for (int c = 0; c < 2 * NCH; ++c) x[c] = __builtin_fma(-kb, y[c], x[c]);
+      for (int c = 0; c < 2 * NC; ++c) x[c] = __builtin_fma(-kb, y[c], x[c]);
     }
 
     if (live) {
-      store_row<NCH, VEC>(a.Xout + (size_t)row * M, M, q, x);
-      if (q == 0) a.xout[row] = xm;
+      store_row<L, NC, VEC>(a.Xout + (size_t)row * M, M, j, x);
+      if (j == 0) a.xout[row] = xm;
     }
   }
 }
 
 // ---------------------------------------------------------------------------
 // Diag: the batch's own nb obs rows, serial in k.  One workgroup, quad per row.
-// LDS: ye_cur[2][S], mye[2], tw[nb][nb] (GC only).
+//
+// The serial chain is kept short:
+//  - the quad that owns row k+1 computes that row's variance and the scalar gain
+//    factors right after it has applied ob k and publishes (ye, mye, mean(ye),
+//    innov, rden, beta) through LDS; every other quad only does dot + update;
+//  - one barrier per step and NO vector-memory operation inside the loop (the
+//    workgroup barrier implies vmcnt(0): a global store per step would put its
+//    completion latency on every step).  Published ye rows stay in an LDS ring
+//    [nb][S] and are copied to Ye_rec after the loop; per-ob scalars stay in the
+//    owner's registers;
+//  - the row mean that np.var needs is carried incrementally
+//    (mean(y - kb*ye) = mean(y) - kb*mean(ye)), so the variance is one reduction;
+//  - the ob's own posterior variance is (1-kb)^2 * var (its row is scaled by
+//    1-kb, ensrf.py:141), not a second reduction.
+// LDS: ye_ring[nb][S], sc[nb][8], tw[nb][nb] (GC only).
 // ---------------------------------------------------------------------------
-template <int NCH, bool VEC>
+template <int NC, bool VEC>
 __global__ __launch_bounds__(kThreads) void k_diag(const DiagArgs a) {
   extern __shared__ __align__(16) double smem[];
-  constexpr int S = 8 * NCH;
-  double* ye_cur = smem;            // [2][S]
-  double* mye_s = smem + 2 * S;     // [2] (+2 pad)
-  double* tw = smem + 2 * S + 4;    // [nb][nb]
+  constexpr int L = 4;
+  constexpr int S = 2 * L * NC;
+  const int nb = a.nb;
+  double* ye_ring = smem;                  // [nb][S]
+  double* sc = smem + (size_t)nb * S;      // [nb][8]: mye, ymean, innov, rden, beta, active
+  double* tw = sc + (size_t)nb * 8;        // [nb][nb]
   const int tid = threadIdx.x;
   const int q = tid & 3;
   const int r = tid >> 2;
   const int M = a.M;
-  const int nb = a.nb;
   const bool live = r < nb;
   const long row = a.b0 + r;
   const double rM1 = 1.0 / (double)(M - 1);
-  const double invM = (double)M;
+  const double dM = (double)M;
+  const double invM = 1.0 / dM;
 
   if (a.loc_mode != 0) {
-    // taper of ob k (row index k) against ob j of the batch: observation.py:68-83
+    // taper of ob k against ob j of the batch: observation.py:68-83
     for (int i = tid; i < nb * nb; i += kThreads) {
-      const int k = i / nb, j = i - k * nb;
-      const double d = haversine_km(a.ob_lat[a.b0 + k], a.ob_lon[a.b0 + k], a.ob_lat[a.b0 + j],
-                                    a.ob_lon[a.b0 + j]);
+      const int k = i / nb, jj = i - k * nb;
+      const double d = haversine_km(a.ob_lat[a.b0 + k], a.ob_lon[a.b0 + k], a.ob_lat[a.b0 + jj],
+                                    a.ob_lon[a.b0 + jj]);
       tw[i] = gaspari_cohn(d, a.ob_hw[a.b0 + k]);
     }
   }
 
-  double x[2 * NCH];
-  double xm = 0.0;
+  double x[2 * NC];
+  double xm = 0.0, my_val = 0.0, my_err = 1.0;
+  bool my_asm = false;
   if (live) {
-    load_row<NCH, VEC>(a.Yp + (size_t)row * M, M, q, x);
+    load_row<L, NC, VEC>(a.Yp + (size_t)row * M, M, q, x);
     xm = a.ym[row];
+    my_val = a.ob_value[row];
+    my_err = a.ob_error[row];
+    my_asm = a.ob_assim[row] != 0;
   } else {
 #pragma unroll
-    for (int c = 0; c < 2 * NCH; ++c) x[c] = 0.0;
+    for (int c = 0; c < 2 * NC; ++c) x[c] = 0.0;
   }
-  // validity mask of this lane's slots (padding slots must not enter np.var)
-  bool valid[2 * NCH];
+  double rmean = group_rowsum<L, NC>(x) / dM;  // padding slots hold 0
+
+  double o_prior_mean = 0.0, o_prior_var = 0.0, o_innov = 0.0, o_rden = 0.0, o_beta = 0.0;
+  double o_post_mean = 0.0, o_post_var = 0.0;
+  bool o_done = false;
+
+  // publish(k): called by the quad that owns row k, with its row current through ob k-1
+  auto publish = [&](int k) {
+    double* yb = ye_ring + (size_t)k * S;
 #pragma unroll
-  for (int c = 0; c < NCH; ++c) {
-    valid[2 * c] = (8 * c + 2 * q) < M;
-    valid[2 * c + 1] = (8 * c + 2 * q + 1) < M;
-  }
+    for (int c = 0; c < NC; ++c)
+      *reinterpret_cast<double2*>(yb + 2 * L * c + 2 * q) = make_double2(x[2 * c], x[2 * c + 1]);
+    // np.var, ddof=0 (:69).  Padding slots hold exactly 0, so they add mean^2 each: remove it.
+    const double ss = group_sumsq_about<L, NC>(x, rmean) - (double)(S - M) * (rmean * rmean);
+    const double varye = ss * invM;
+    const double innov = my_val - xm;                                       // :85
+    const double kdenom = varye + my_err;                                   // :91
+    const double rden = 1.0 / kdenom;
+    const double beta = 1.0 / (1.0 + sqrt(my_err * rden));                  // :135
+    if (q == 0) {
+      double* s = sc + (size_t)k * 8;
+      s[0] = xm;
+      s[1] = rmean;
+      s[2] = innov;
+      s[3] = rden;
+      s[4] = beta;
+      s[5] = my_asm ? 1.0 : 0.0;
+    }
+    o_prior_mean = xm;     // :66
+    o_prior_var = varye;   // :70
+    o_innov = innov;
+    o_rden = rden;
+    o_beta = beta;
+  };
+
+  if (r == 0) publish(0);
 
   for (int k = 0; k < nb; ++k) {
-    double* yb = ye_cur + (k & 1) * S;
-    if (r == k) {
-#pragma unroll
-      for (int c = 0; c < NCH; ++c)
-        *reinterpret_cast<double2*>(yb + 8 * c + 2 * q) = make_double2(x[2 * c], x[2 * c + 1]);
-      if (q == 0) mye_s[k & 1] = xm;
-    }
     __syncthreads();
-    double y[2 * NCH];
+    const double* s = sc + (size_t)k * 8;
+    const bool active = s[5] != 0.0;  // uniform
+    if (active) {
+      double y[2 * NC];
+      lds_read_row<L, NC>(ye_ring + (size_t)k * S, q, y);
+      const double dot = group_dot<L, NC>(x, y);
+      double kc = dot * rM1;                                                 // :95
+      if (a.loc_mode != 0) kc = (live ? tw[k * nb + r] : 0.0) * kc;          // :115
+      const double km = kc * s[3];                                           // :119
+      xm = xm + km * s[2];                                                   // :130
+      const double kb = s[4] * km;                                           // :136
+      rmean = __builtin_fma(-kb, s[1], rmean);
 #pragma unroll
-    for (int c = 0; c < NCH; ++c) {
-      const double2 v = *reinterpret_cast<const double2*>(yb + 8 * c + 2 * q);
-      y[2 * c] = v.x;
-      y[2 * c + 1] = v.y;
-    }
-    const double mye = mye_s[k & 1];
-    // varye = np.var(ye): two-pass, ddof = 0 (ensrf.py:69)
-    double s = 0.0;
-#pragma unroll
-    for (int c = 0; c < 2 * NCH; ++c) s += y[c];
-    const double ymean = quad_sum(s) / invM;
-    double ss = 0.0;
-#pragma unroll
-    for (int c = 0; c < 2 * NCH; ++c) {
-      const double d = valid[c] ? (y[c] - ymean) : 0.0;
-      ss = __builtin_fma(d, d, ss);
-    }
-    const double varye = quad_sum(ss) / invM;
-    const long ob = a.b0 + k;
-    const bool owner = (r == k);
-    if (owner) {
-      // Ye_rec row + prior diagnostics (ensrf.py:66,70)
-      double* yr = a.Ye_rec + (size_t)ob * M;
-      store_row<NCH, VEC>(yr, M, q, y);
-      if (q == 0) {
-        a.prior_mean[ob] = mye;
-        a.prior_var[ob] = varye;
+      for (int c = 0; c < 2 * NC; ++c) x[c] = __builtin_fma(-kb, y[c], x[c]);  // :141
+      if (r == k) {
+        // posterior diagnostics of ob k (:144-149): its own row was scaled by (1 - kb)
+        const double f = 1.0 - kb;
+        o_post_var = (f * f) * o_prior_var;
+        o_post_mean = xm;
+        o_done = true;
       }
     }
-    const bool assim = a.ob_assim[ob] != 0;
-    if (!assim) {  // ensrf.py:74-76 (uniform branch)
-      if (owner && q == 0) {
-        a.assimilated[ob] = 0;
-        double* ck = a.coef + (size_t)ob * kCoefStride;
-        ck[0] = 0.0; ck[1] = 0.0; ck[2] = 0.0; ck[3] = 0.0;
-      }
-      continue;
-    }
-    const double obs_err = a.ob_error[ob];
-    const double innov = a.ob_value[ob] - mye;       // :85
-    const double kdenom = varye + obs_err;           // :91
-    const double rden = 1.0 / kdenom;
-    const double beta = 1.0 / (1.0 + sqrt(obs_err / (varye + obs_err)));  // :135
-    if (owner && q == 0) {
-      double* ck = a.coef + (size_t)ob * kCoefStride;
-      ck[0] = innov; ck[1] = rden; ck[2] = beta; ck[3] = 1.0;
-    }
-    // update every row of the batch (its own row included, taper(k,k) = 1)
-    const double dot = quad_dot<NCH>(x, y);
-    double kc = dot * rM1;
-    if (a.loc_mode != 0) kc = (live ? tw[k * nb + r] : 0.0) * kc;
-    const double km = kc * rden;
-    xm = xm + km * innov;
-    const double kb = beta * km;
-#pragma unroll
-    for (int c = 0; c < 2 * NCH; ++c) x[c] = __builtin_fma(-kb, y[c], x[c]);
-    if (owner) {
-      // posterior diagnostics of ob k (ensrf.py:144-149)
-      double s2 = 0.0;
-#pragma unroll
-      for (int c = 0; c < 2 * NCH; ++c) s2 += x[c];
-      const double pm = quad_sum(s2) / invM;
-      double ss2 = 0.0;
-#pragma unroll
-      for (int c = 0; c < 2 * NCH; ++c) {
-        const double d = valid[c] ? (x[c] - pm) : 0.0;
-        ss2 = __builtin_fma(d, d, ss2);
-      }
-      const double pv = quad_sum(ss2) / invM;
-      if (q == 0) {
-        a.post_mean[ob] = xm;
-        a.post_var[ob] = pv;
-        a.assimilated[ob] = 1;
+    if (r == k + 1 && k + 1 < nb) publish(k + 1);
+  }
+  __syncthreads();
+
+  // write-back: recorded trajectory, rows, per-ob scalars
+  {
+    const int S2 = S / 2;
+    for (int i = tid; i < nb * S2; i += kThreads) {
+      const int k = i / S2, m = 2 * (i - k * S2);
+      double* dst = a.Ye_rec + (size_t)(a.b0 + k) * M;
+      const double2 v = *reinterpret_cast<const double2*>(ye_ring + (size_t)k * S + m);
+      if (VEC) {
+        if (m < M) *reinterpret_cast<double2*>(dst + m) = v;
+      } else {
+        if (m < M) dst[m] = v.x;
+        if (m + 1 < M) dst[m + 1] = v.y;
       }
     }
   }
-
   if (live) {
-    store_row<NCH, VEC>(a.Yp + (size_t)row * M, M, q, x);
-    if (q == 0) a.ym[row] = xm;
+    store_row<L, NC, VEC>(a.Yp + (size_t)row * M, M, q, x);
+    if (q == 0) {
+      a.ym[row] = xm;
+      a.prior_mean[row] = o_prior_mean;
+      a.prior_var[row] = o_prior_var;
+      double* ck = a.coef + (size_t)row * kCoefStride;
+      ck[0] = my_asm ? o_innov : 0.0;
+      ck[1] = my_asm ? o_rden : 0.0;
+      ck[2] = my_asm ? o_beta : 0.0;
+      ck[3] = my_asm ? 1.0 : 0.0;
+      a.assimilated[row] = o_done ? 1 : 0;   // :74-76, :149
+      if (o_done) {
+        a.post_mean[row] = o_post_mean;
+        a.post_var[row] = o_post_var;
+      }
+    }
   }
-}
-
-template <int NCH>
-hipError_t sweep_nch(const SweepArgs& a, bool vec, hipStream_t s) {
-  const long nblocks = (a.nrows + kRowsPerBlock - 1) / kRowsPerBlock;
-  const size_t lds = ((size_t)a.nb * 8 * NCH + (size_t)a.nb * kCoefStride) * sizeof(double);
-  long grid = nblocks < 256L * 8 ? nblocks : 256L * 8;
-  if (grid < 1) grid = 1;
-  if (vec)
-    hipLaunchKernelGGL((k_sweep<NCH, true>), dim3((unsigned)grid), dim3(kThreads), lds, s, a);
-  else
-    hipLaunchKernelGGL((k_sweep<NCH, false>), dim3((unsigned)grid), dim3(kThreads), lds, s, a);
-  return hipGetLastError();
-}
-
-template <int NCH>
-hipError_t diag_nch(const DiagArgs& a, bool vec, hipStream_t s) {
-  const size_t lds = (2 * 8 * NCH + 4 + (a.loc_mode ? (size_t)a.nb * a.nb : 0)) * sizeof(double);
-  if (vec)
-    hipLaunchKernelGGL((k_diag<NCH, true>), dim3(1), dim3(kThreads), lds, s, a);
-  else
-    hipLaunchKernelGGL((k_diag<NCH, false>), dim3(1), dim3(kThreads), lds, s, a);
-  return hipGetLastError();
 }
 
 inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
+
+template <int L, int NC>
+hipError_t sweep_launch(const SweepArgs& a, bool vec, hipStream_t s) {
+  constexpr int kRowsPerBlock = kThreads / L;
+  const long nblocks = (a.nrows + kRowsPerBlock - 1) / kRowsPerBlock;
+  const size_t lds = ((size_t)a.nb * 2 * L * NC + (size_t)a.nb * kCoefStride) * sizeof(double);
+  long grid = nblocks < 256L * 8 ? nblocks : 256L * 8;
+  if (grid < 1) grid = 1;
+  if (lds > 64 * 1024) {
+    hipError_t e = vec ? hipFuncSetAttribute(reinterpret_cast<const void*>(&k_sweep<L, NC, true>),
+                                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)
+                       : hipFuncSetAttribute(reinterpret_cast<const void*>(&k_sweep<L, NC, false>),
+                                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return e;
+  }
+  if (vec)
+    hipLaunchKernelGGL((k_sweep<L, NC, true>), dim3((unsigned)grid), dim3(kThreads), lds, s, a);
+  else
+    hipLaunchKernelGGL((k_sweep<L, NC, false>), dim3((unsigned)grid), dim3(kThreads), lds, s, a);
+  return hipGetLastError();
+}
+
+template <int NC>
+hipError_t sweep4(const SweepArgs& a, bool vec, hipStream_t s) { return sweep_launch<4, NC>(a, vec, s); }
+
+template <int NC>
+hipError_t diag_nc(const DiagArgs& a, bool vec, hipStream_t s) {
+  const size_t lds = diag_lds_bytes(8 * NC, a.nb, a.loc_mode);
+  if (lds > 64 * 1024) {
+    hipError_t e;
+    if (vec)
+      e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_diag<NC, true>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    else
+      e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_diag<NC, false>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return e;
+  }
+  if (vec)
+    hipLaunchKernelGGL((k_diag<NC, true>), dim3(1), dim3(kThreads), lds, s, a);
+  else
+    hipLaunchKernelGGL((k_diag<NC, false>), dim3(1), dim3(kThreads), lds, s, a);
+  return hipGetLastError();
+}
 
 }  // namespace
 
@@ -347,25 +461,29 @@ inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 
     default: return hipErrorInvalidValue;                        \
   }
 
-static int round_nch(int M) {
+int sweep_slots(int M) {  // padded row length (doubles) of the quad layout's LDS image
   int nch = (M + 7) / 8;
   if (nch > 16) nch = (nch <= 20) ? 20 : (nch <= 24) ? 24 : 32;
-  return nch;
+  return 8 * nch;
+}
+
+size_t diag_lds_bytes(int slots, int nb, int loc_mode) {
+  return ((size_t)nb * slots + (size_t)nb * 8 + (loc_mode ? (size_t)nb * nb : 0)) * sizeof(double);
 }
 
 hipError_t launch_sweep(const SweepArgs& a, hipStream_t s) {
   if (a.M < 2 || a.M > kMaxMembers || a.nb < 1 || a.nb > kMaxBatch) return hipErrorInvalidValue;
   if (a.nrows <= 0) return hipSuccess;
-  const bool vec = (a.M % 2 == 0) && aligned16(a.Xin) && aligned16(a.Xout);
-  const int nch = round_nch(a.M);
-  EFA_NCH_SWITCH(sweep_nch, a, vec, s)
+  const bool vec = (a.M % 2 == 0) && aligned16(a.Xin) && aligned16(a.Xout) && aligned16(a.Ye);
+  const int nch = sweep_slots(a.M) / 8;
+  EFA_NCH_SWITCH(sweep4, a, vec, s)
 }
 
 hipError_t launch_diag(const DiagArgs& a, hipStream_t s) {
   if (a.M < 2 || a.M > kMaxMembers || a.nb < 1 || a.nb > kMaxBatch) return hipErrorInvalidValue;
   const bool vec = (a.M % 2 == 0) && aligned16(a.Yp) && aligned16(a.Ye_rec);
-  const int nch = round_nch(a.M);
-  EFA_NCH_SWITCH(diag_nch, a, vec, s)
+  const int nch = sweep_slots(a.M) / 8;
+  EFA_NCH_SWITCH(diag_nc, a, vec, s)
 }
 
 }  // namespace efa

@@ -37,25 +37,25 @@ struct TShape {
   static constexpr size_t lds_doubles = (size_t)kSteps * NT * 64;
 };
 
+// Loads of one tile are branch-free (clamped addresses; the partial last chunk is zeroed
+// by a select at the point of use) and the prefetch is unconditional, so the compiler can
+// keep the next tile's 16-byte loads in flight behind counted vmcnt waits while the current
+// tile is multiplied.  With conditional loads it falls back to vmcnt(0) and the overlap is lost.
 template <int NU>
-__device__ __forceinline__ void load_tile(const double* __restrict__ X, long row, bool row_ok, int M, int g,
+__device__ __forceinline__ void load_tile(const double* __restrict__ X, long row_clamped, int M, int g,
                                           double (&a)[2 * NU]) {
-  const double* p = X + (size_t)row * M;
+  const double* p = X + (size_t)row_clamped * M;
 #pragma unroll
   for (int u = 0; u < NU; ++u) {
-    const int m0 = 8 * u + 2 * g;
-    if (row_ok && m0 < M) {
-      const double2 v = *reinterpret_cast<const double2*>(p + m0);
-      a[2 * u] = v.x;
-      a[2 * u + 1] = v.y;
-    } else {
-      a[2 * u] = 0.0;
-      a[2 * u + 1] = 0.0;
-    }
+    int m0 = 8 * u + 2 * g;
+    if (u == NU - 1) m0 = (m0 < M) ? m0 : M - 2;  // last chunk may be partial: clamp the address
+    const double2 v = *reinterpret_cast<const double2*>(p + m0);
+    a[2 * u] = v.x;
+    a[2 * u + 1] = v.y;
   }
 }
 
-template <int NU>
+template <int NU, bool FUSED>
 __global__ __launch_bounds__(kThreadsT) void k_transform(const TransformArgs p) {
   using Sh = TShape<NU>;
   constexpr int NT = Sh::NT;
@@ -88,30 +88,49 @@ __global__ __launch_bounds__(kThreadsT) void k_transform(const TransformArgs p) 
   const long wave = (long)blockIdx.x * (kThreadsT / 64) + (tid >> 6);
   const long nwaves = (long)gridDim.x * (kThreadsT / 64);
   const int tM = M >> 4, nM = M & 15;  // tile / lane column holding the mean increment
+  const long last_row = p.nrows - 1;
+  const bool last_ok = (8 * (NU - 1) + 2 * g) < M;  // this lane's slots of the last chunk are real members
 
   double a[2 * NU], an[2 * NU];
   long tile = wave;
-  if (tile < ntiles) load_tile<NU>(p.Xin, tile * 16 + n, tile * 16 + n < p.nrows, M, g, a);
+  if (tile < ntiles) {
+    const long r = tile * 16 + n;
+    load_tile<NU>(p.Xin, r < last_row ? r : last_row, M, g, a);
+  }
 
   while (tile < ntiles) {
     const long next = tile + nwaves;
-    if (next < ntiles) load_tile<NU>(p.Xin, next * 16 + n, next * 16 + n < p.nrows, M, g, an);
     const long r0 = tile * 16;
-
-    double rmean = 0.0;  // prior mean of row n (fused_members only)
-    if (p.fused_members) {
-      double s = 0.0;
+    double xm4[4] = {0.0, 0.0, 0.0, 0.0};  // prior means of rows 4v+g (perturbation form)
+    if (!FUSED) {
 #pragma unroll
-      for (int c = 0; c < 2 * NU; ++c) s += a[c];
+      for (int v = 0; v < 4; ++v) {
+        const long rr = r0 + 4 * v + g;
+        xm4[v] = p.xin[rr < last_row ? rr : last_row];
+      }
+    }
+    {  // prefetch (the last iteration harmlessly re-reads its own tile)
+      const long r = (next < ntiles ? next : tile) * 16 + n;
+      load_tile<NU>(p.Xin, r < last_row ? r : last_row, M, g, an);
+    }
+    if (!last_ok) {
+      a[2 * NU - 2] = 0.0;
+      a[2 * NU - 1] = 0.0;
+    }
+
+    double rmean = 0.0;  // prior mean of row n (FUSED only)
+    if (FUSED) {
+      double s4[4] = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+      for (int c = 0; c < 2 * NU; ++c) s4[c & 3] += a[c];
+      double s = (s4[0] + s4[1]) + (s4[2] + s4[3]);
       s += __shfl_xor(s, 16, 64);
       s += __shfl_xor(s, 32, 64);
       rmean = s / (double)M;
 #pragma unroll
-      for (int u = 0; u < NU; ++u) {
-        const int m0 = 8 * u + 2 * g;
-        if (m0 < M) a[2 * u] -= rmean;
-        if (m0 + 1 < M) a[2 * u + 1] -= rmean;
-      }
+      for (int c = 0; c < 2 * NU - 2; ++c) a[c] -= rmean;
+      a[2 * NU - 2] = last_ok ? a[2 * NU - 2] - rmean : 0.0;
+      a[2 * NU - 1] = last_ok ? a[2 * NU - 1] - rmean : 0.0;
     }
 
     v4f64 acc[NT];
@@ -125,48 +144,51 @@ __global__ __launch_bounds__(kThreadsT) void k_transform(const TransformArgs p) 
         acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[s], b, acc[t], 0, 0, 0);
       }
       // keep the scheduler from hoisting all 2*NU*NT LDS reads (register blow-up)
-      if ((s & 1) == 1) __builtin_amdgcn_sched_barrier(0);
+      __builtin_amdgcn_sched_barrier(0);
     }
 
     // acc[t][v] = D[row 4v+g][col 16t+n]  (layout probed on gfx950: tools/mfma_probe.hip)
-    double dm[4];  // mean increment of rows 4v+g : column M of the product
-#pragma unroll
-    for (int v = 0; v < 4; ++v) dm[v] = 0.0;
-#pragma unroll
-    for (int t = 0; t < NT; ++t) {
-      if (t == tM) {
-#pragma unroll
-        for (int v = 0; v < 4; ++v) dm[v] = __shfl(acc[t][v], (lane & 48) | nM, 64);
-      }
-    }
-    double base[4];
+    double base[4];  // posterior mean of rows 4v+g: prior mean + column M of the product
 #pragma unroll
     for (int v = 0; v < 4; ++v) {
-      const long row = r0 + 4 * v + g;
-      double m0;
-      if (p.fused_members) m0 = __shfl(rmean, 4 * v + g, 64);
-      else m0 = (row < p.nrows) ? p.xin[row] : 0.0;
-      base[v] = m0 + dm[v];
-    }
+      double dm = 0.0;
 #pragma unroll
-    for (int t = 0; t < NT; ++t) {
-      const int col = 16 * t + n;
-      if (col < M) {
+      for (int t = 0; t < NT; ++t)
+        if (t == tM) dm = __shfl(acc[t][v], (lane & 48) | nM, 64);
+      const double m0 = FUSED ? __shfl(rmean, 4 * v + g, 64) : xm4[v];
+      base[v] = m0 + dm;
+    }
+    if (r0 + 16 <= p.nrows) {  // full tile: no row checks (wave-uniform)
+#pragma unroll
+      for (int t = 0; t < NT; ++t) {
+        const int col = 16 * t + n;
+        if (col < M) {
+#pragma unroll
+          for (int v = 0; v < 4; ++v)
+            p.Xout[(size_t)(r0 + 4 * v + g) * M + col] = FUSED ? (base[v] + acc[t][v]) : acc[t][v];
+        }
+      }
+      if (!FUSED && n == 0) {
+#pragma unroll
+        for (int v = 0; v < 4; ++v) p.xout[r0 + 4 * v + g] = base[v];
+      }
+    } else {
+#pragma unroll
+      for (int t = 0; t < NT; ++t) {
+        const int col = 16 * t + n;
 #pragma unroll
         for (int v = 0; v < 4; ++v) {
           const long row = r0 + 4 * v + g;
-          if (row < p.nrows) {
-            const double val = p.fused_members ? (base[v] + acc[t][v]) : acc[t][v];
-            p.Xout[(size_t)row * M + col] = val;
-          }
+          if (col < M && row < p.nrows)
+            p.Xout[(size_t)row * M + col] = FUSED ? (base[v] + acc[t][v]) : acc[t][v];
         }
       }
-    }
-    if (!p.fused_members && n == 0) {
+      if (!FUSED && n == 0) {
 #pragma unroll
-      for (int v = 0; v < 4; ++v) {
-        const long row = r0 + 4 * v + g;
-        if (row < p.nrows) p.xout[row] = base[v];
+        for (int v = 0; v < 4; ++v) {
+          const long row = r0 + 4 * v + g;
+          if (row < p.nrows) p.xout[row] = base[v];
+        }
       }
     }
 
@@ -176,12 +198,12 @@ __global__ __launch_bounds__(kThreadsT) void k_transform(const TransformArgs p) 
   }
 }
 
-template <int NU>
-hipError_t transform_nu(const TransformArgs& a, hipStream_t s) {
+template <int NU, bool FUSED>
+hipError_t transform_launch(const TransformArgs& a, hipStream_t s) {
   using Sh = TShape<NU>;
   const size_t lds = Sh::lds_doubles * sizeof(double);
   if (lds > 64 * 1024) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_transform<NU>),
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_transform<NU, FUSED>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
   }
@@ -190,8 +212,13 @@ hipError_t transform_nu(const TransformArgs& a, hipStream_t s) {
   long grid = (ntiles + 7) / 8;
   if (grid > 256L * per_cu) grid = 256L * per_cu;
   if (grid < 1) grid = 1;
-  hipLaunchKernelGGL((k_transform<NU>), dim3((unsigned)grid), dim3(kThreadsT), lds, s, a);
+  hipLaunchKernelGGL((k_transform<NU, FUSED>), dim3((unsigned)grid), dim3(kThreadsT), lds, s, a);
   return hipGetLastError();
+}
+
+template <int NU>
+hipError_t transform_nu(const TransformArgs& a, hipStream_t s) {
+  return a.fused_members ? transform_launch<NU, true>(a, s) : transform_launch<NU, false>(a, s);
 }
 
 }  // namespace

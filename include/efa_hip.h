@@ -73,7 +73,7 @@ int efa_ctx_destroy(efa_ctx *ctx);
 /* issue all work on the caller's hipStream_t (e.g. torch's current stream);
  * NULL restores the context's own stream */
 int efa_ctx_set_stream(efa_ctx *ctx, void *hip_stream);
-/* options: "obs_batch" (obs fused per sweep launch, 1..64, default 32),
+/* options: "obs_batch" (obs fused per sweep launch, 1..64, default 64),
  *          "path" (EFA_PATH_*), "threads_hint" (ignored) */
 int efa_ctx_set_option(efa_ctx *ctx, const char *key, long value);
 int efa_ctx_get_option(efa_ctx *ctx, const char *key, long *value);

@@ -77,7 +77,7 @@ def test_host_abi_matches_reference_goldens(name, path, batch):
     ctx.set_option("path", {"auto": 0, "sweep": 1, "transform": 2}[path])
     diag = ctx.ensrf_update_host(xbm, Xbp, N, g["ob_value"], g["ob_error"], g["ob_assim"], **golden_kwargs(g))
     ctx.set_option("path", 0)
-    ctx.set_option("obs_batch", 32)
+    ctx.set_option("obs_batch", 64)
     assert_parity(xbm, g["xam"], name + " xam")
     if "Xap" in g:
         assert_parity(Xbp, g["Xap"], name + " Xap")
@@ -202,7 +202,7 @@ def _run_hip(c, path="auto", batch=32):
                   grid_lat=c["lat"].reshape(-1), grid_lon=c["lon"].reshape(-1), n_lead=c["n_lead"])
     diag = ctx.ensrf_update_host(xbm, Xbp, c["N"], c["val"], c["err"], c["asm"], **kw)
     ctx.set_option("path", 0)
-    ctx.set_option("obs_batch", 32)
+    ctx.set_option("obs_batch", 64)
     return xbm, Xbp, diag
 
 
@@ -282,7 +282,7 @@ def test_logical_shards_equal_unsharded_bit_for_bit():
     ctx.set_option("path", 1)
     N, M, P, ncol, L = c["N"], c["M"], c["P"], 800, 3
     xbm, Xbp = orc.format_prior_state(c["X"], c["HX"])
-    full_x, full_X, _ = _run_hip(c, path="sweep")
+    full_x, full_X, _ = _run_hip(c, path="sweep", batch=64)
     lat, lon = c["lat"].reshape(-1), c["lon"].reshape(-1)
     out_x = np.empty(N)
     out_X = np.empty((N, M))
