@@ -79,6 +79,9 @@ struct efa_ctx {
   long obs_batch = 64;
   long path = EFA_PATH_AUTO;
   long timing = 0;
+  long use_pipeline = 1;   // persistent Phase-A kernel when it applies (else per-batch kernels)
+  long spin_limit = 4000000;
+  long pipe_debug = 0;
 
   // --- trajectory recorded by the last obs phase --------------------------
   bool have_traj = false;
@@ -89,6 +92,10 @@ struct efa_ctx {
   bool have_transform = false;   // identity rows were carried: (T, w) valid
   std::vector<uint8_t> h_assim;  // host copy of ob_assim
   DevBuf Ye_rec, coef;           // [P][M], [P][4]
+  DevBuf traj, tw_mat, status;   // pipeline: trajectory records, GC obs-obs taper, status words
+  const double* ye_ptr = nullptr;  // where Phase B reads the recorded ye rows
+  long ye_stride = 0;
+  int phase_a_kind = 0;          // 1 pipeline, 2 per-batch kernels
   DevBuf ob_val, ob_err, ob_asm, ob_lat, ob_lon, ob_hw;  // device copies [P]
   DevBuf d_prior_mean, d_prior_var, d_post_mean, d_post_var, d_assimilated;
   DevBuf Yw, ymw;  // obs block workspace [(P+M)][M], [(P+M)]
@@ -204,8 +211,62 @@ int obs_phase(efa_ctx* c, int M, long P, double* ym_dev, double* Yp_dev, const d
   EFA_HIP(hipMemcpyAsync(ymw, ym_dev, dP, hipMemcpyDeviceToDevice, s));
   if (carry_T) EFA_HIP(launch_set_identity(M, Yw + (size_t)P * M, ymw + P, s));
 
+  // ---- persistent pipeline (one launch for all P obs) ---------------------------------
+  bool done_by_pipeline = false;
+  const bool tw_fits = (loc_mode != EFA_LOC_GC) || ((size_t)P * (size_t)R * sizeof(double) <= ((size_t)3 << 30));
+  if (c->use_pipeline && pipeline_supported(M, R) && tw_fits) {
+    const long TS = traj_stride(M);
+    EFA_TRY(c->traj.reserve((size_t)P * TS * sizeof(unsigned long long)));
+    EFA_TRY(c->status.reserve(2 * sizeof(int)));
+    EFA_HIP(launch_fill_u64(c->traj.as<unsigned long long>(), (size_t)P * TS, kTrajSentinel, s));
+    EFA_HIP(hipMemsetAsync(c->status.p, 0, 2 * sizeof(int), s));
+    PipeArgs pa{};
+    pa.Yp = Yw;
+    pa.ym = ymw;
+    pa.R = R;
+    pa.P = P;
+    pa.M = M;
+    pa.ob_value = c->ob_val.as<double>();
+    pa.ob_error = c->ob_err.as<double>();
+    pa.ob_assim = c->ob_asm.as<uint8_t>();
+    pa.loc_mode = loc_mode;
+    pa.tw = nullptr;
+    if (loc_mode == EFA_LOC_GC) {
+      EFA_TRY(c->tw_mat.reserve((size_t)P * R * sizeof(double)));
+      EFA_HIP(launch_obs_taper_matrix(P, R, c->ob_lat.as<double>(), c->ob_lon.as<double>(), c->ob_hw.as<double>(),
+                                      c->tw_mat.as<double>(), s));
+      pa.tw = c->tw_mat.as<double>();
+    }
+    pa.traj = c->traj.as<unsigned long long>();
+    pa.coef = c->coef.as<double>();
+    pa.prior_mean = c->d_prior_mean.as<double>();
+    pa.prior_var = c->d_prior_var.as<double>();
+    pa.post_mean = c->d_post_mean.as<double>();
+    pa.post_var = c->d_post_var.as<double>();
+    pa.assimilated = c->d_assimilated.as<uint8_t>();
+    pa.status = c->status.as<int>();
+    pa.spin_limit = c->spin_limit;
+    pa.debug = (int)c->pipe_debug;
+    EFA_HIP(launch_pipeline(pa, s));
+    int st[2] = {0, 0};
+    EFA_HIP(hipMemcpyAsync(st, c->status.p, sizeof(st), hipMemcpyDeviceToHost, s));
+    EFA_HIP(hipStreamSynchronize(s));
+    if (st[0] == 0 && st[1] == 0) {
+      done_by_pipeline = true;
+      c->ye_ptr = reinterpret_cast<const double*>(c->traj.p);
+      c->ye_stride = TS;
+      c->phase_a_kind = 1;
+    }
+    // else: a bounded spin expired (co-residency lost?).  The kernel wrote nothing back;
+    // fall through to the per-batch kernels on the untouched obs block.
+  }
+  if (!done_by_pipeline) {
+    c->ye_ptr = c->Ye_rec.as<double>();
+    c->ye_stride = M;
+    c->phase_a_kind = 2;
+  }
   const long B = effective_batch(c, M);
-  for (long b0 = 0; b0 < P; b0 += B) {
+  for (long b0 = 0; !done_by_pipeline && b0 < P; b0 += B) {
     const int nb = (int)((P - b0 < B) ? (P - b0) : B);
     DiagArgs d{};
     d.Yp = Yw;
@@ -240,6 +301,7 @@ int obs_phase(efa_ctx* c, int M, long P, double* ym_dev, double* Yp_dev, const d
     a.nrows = R;
     a.M = M;
     a.Ye = c->Ye_rec.as<double>() + (size_t)b0 * M;
+    a.ye_stride = M;
     a.coef = c->coef.as<double>() + (size_t)b0 * kCoefStride;
     a.nb = nb;
     a.taper_mode = (loc_mode == EFA_LOC_GC) ? kTaperObs : kTaperNone;
@@ -321,7 +383,8 @@ int state_sweeps(efa_ctx* c, long rows, const double* xm_in, const double* Xp_in
     a.xout = xm_out;
     a.nrows = rows;
     a.M = M;
-    a.Ye = c->Ye_rec.as<double>() + (size_t)b0 * M;
+    a.Ye = c->ye_ptr + (size_t)b0 * c->ye_stride;
+    a.ye_stride = c->ye_stride;
     a.coef = c->coef.as<double>() + (size_t)b0 * kCoefStride;
     a.nb = nb;
     a.skip_lo = a.skip_hi = -1;
@@ -452,7 +515,7 @@ int efa_ctx_destroy(efa_ctx* c) {
   if (c->stream) (void)hipStreamSynchronize(c->stream);
   DevBuf* bufs[] = {&c->Ye_rec, &c->coef, &c->ob_val, &c->ob_err, &c->ob_asm, &c->ob_lat, &c->ob_lon, &c->ob_hw,
                     &c->d_prior_mean, &c->d_prior_var, &c->d_post_mean, &c->d_post_var, &c->d_assimilated,
-                    &c->Yw, &c->ymw, &c->W, &c->glat, &c->glon, &c->xm_ws, &c->h_xm, &c->h_Xp, &c->h_ym, &c->h_Yp};
+                    &c->Yw, &c->ymw, &c->traj, &c->tw_mat, &c->status, &c->W, &c->glat, &c->glon, &c->xm_ws, &c->h_xm, &c->h_Xp, &c->h_ym, &c->h_Yp};
   for (DevBuf* b : bufs) b->release();
   for (int i = 0; i < 4; ++i)
     if (c->ev[i]) (void)hipEventDestroy(c->ev[i]);
@@ -478,6 +541,13 @@ int efa_ctx_set_option(efa_ctx* c, const char* key, long value) {
     c->path = value;
   } else if (!strcmp(key, "timing")) {
     c->timing = value ? 1 : 0;
+  } else if (!strcmp(key, "pipeline")) {
+    c->use_pipeline = value ? 1 : 0;
+  } else if (!strcmp(key, "pipe_debug")) {
+    c->pipe_debug = value;
+  } else if (!strcmp(key, "spin_limit")) {
+    if (value < 1) return fail(EFA_ERR_INVALID, "spin_limit must be positive");
+    c->spin_limit = value;
   } else if (!strcmp(key, "threads_hint")) {
   } else {
     return fail(EFA_ERR_INVALID, "unknown option '%s'", key);
@@ -491,6 +561,8 @@ int efa_ctx_get_option(efa_ctx* c, const char* key, long* value) {
   if (!strcmp(key, "obs_batch")) *value = c->obs_batch;
   else if (!strcmp(key, "path")) *value = c->path;
   else if (!strcmp(key, "timing")) *value = c->timing;
+  else if (!strcmp(key, "pipeline")) *value = c->use_pipeline;
+  else if (!strcmp(key, "phase_a_kind")) *value = c->phase_a_kind;
   else if (!strcmp(key, "device")) *value = c->device;
   else return fail(EFA_ERR_INVALID, "unknown option '%s'", key);
   return EFA_OK;

@@ -31,7 +31,8 @@ struct SweepArgs {
   double* xout;
   long nrows;
   int M;
-  const double* Ye;    // [nb][M] recorded obs-space perturbations of the batch
+  const double* Ye;    // [nb][ye_stride] recorded obs-space perturbations of the batch
+  long ye_stride;      // doubles between consecutive ye rows (>= M)
   const double* coef;  // [nb][kCoefStride]
   int nb;
   int taper_mode;
@@ -67,6 +68,47 @@ struct DiagArgs {
   double* post_var;
   uint8_t* assimilated;
 };
+
+// ---- persistent Phase-A pipeline (efa_pipeline.hip) --------------------------------
+// Trajectory record of ob k in global memory: kTrajPad doubles of ye (zero padded) followed
+// by 8 scalars.  Every 8-byte element is written once with an agent-scope store and is
+// pre-filled with kTrajSentinel, so a reader validates each element on its own: no flag,
+// no ordering between the elements (MI355X_MICROARCH.md, "R2 granule").
+constexpr unsigned long long kTrajSentinel = 0x7FF8DEADBEEF0001ull;  // a NaN payload no arithmetic produces
+constexpr int kTrajScalars = 8;  // mye, mean(ye), innov, rden, beta, active, prior_var, (unused)
+inline int traj_pad(int M) { return 16 * ((M + 15) / 16); }             // 8 lanes x 2 doubles per chunk
+inline long traj_stride(int M) { return traj_pad(M) + kTrajScalars; }
+constexpr int kPipeRowsPerWG = 64;
+constexpr int kPipeMaxWGs = 256;  // one 512-thread workgroup per CU: all co-resident
+
+struct PipeArgs {
+  double* Yp;   // [R][M] obs block (+ extra identity rows), in/out
+  double* ym;   // [R]
+  long R;       // rows swept (P + extra)
+  long P;       // observations
+  int M;
+  const double* ob_value;  // device [P]
+  const double* ob_error;
+  const uint8_t* ob_assim;
+  int loc_mode;
+  const double* tw;  // GC: dense obs-obs taper [P][R] (row k = ob k against every row); else null
+  unsigned long long* traj;  // [P][traj_stride(M)] sentinel-filled
+  double* coef;         // [P][kCoefStride] out
+  double* prior_mean;   // [P] out
+  double* prior_var;
+  double* post_mean;
+  double* post_var;
+  uint8_t* assimilated;
+  int* status;          // [2]: [0] abort flag (in-kernel), [1] 0 ok / 1 timeout
+  long spin_limit;
+  int debug;  // diagnostic bits (single-workgroup timing runs only): 1 no global publication, 2 no prefetch
+};
+
+hipError_t launch_pipeline(const PipeArgs& a, hipStream_t s);
+bool pipeline_supported(int M, long R);
+hipError_t launch_fill_u64(unsigned long long* p, size_t n, unsigned long long v, hipStream_t s);
+hipError_t launch_obs_taper_matrix(long P, long R, const double* ob_lat, const double* ob_lon,
+                                   const double* ob_hw, double* tw, hipStream_t s);
 
 struct TransformArgs {
   const double* Xin;  // [rows][M] perturbations, or full members when fused_members

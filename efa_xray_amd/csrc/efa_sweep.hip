@@ -21,122 +21,13 @@
 //           used when there are too few rows to fill the chip (the obs block).
 #include "efa_device.h"
 #include "efa_internal.h"
+#include "efa_rows.h"
 
 namespace efa {
 
 namespace {
 
 constexpr int kThreads = 256;
-
-// ---- group reductions ------------------------------------------------------
-#define EFA_DPP_STEP(v, ctrl)                                                          \
-  do {                                                                                 \
-    int _lo = __double2loint(v), _hi = __double2hiint(v);                              \
-    _lo = __builtin_amdgcn_mov_dpp(_lo, (ctrl), 0xF, 0xF, true);                       \
-    _hi = __builtin_amdgcn_mov_dpp(_hi, (ctrl), 0xF, 0xF, true);                       \
-    v = v + __hiloint2double(_hi, _lo);                                                \
-  } while (0)
-
-template <int L>
-__device__ __forceinline__ double group_sum(double v) {
-  EFA_DPP_STEP(v, 0xB1);  // quad_perm [1,0,3,2]
-  EFA_DPP_STEP(v, 0x4E);  // quad_perm [2,3,0,1]
-  if (L == 16) {
-    EFA_DPP_STEP(v, 0x141);  // row_half_mirror: quads 0<->1, 2<->3
-    EFA_DPP_STEP(v, 0x140);  // row_mirror: the two halves of the 16-lane row
-  }
-  return v;
-}
-
-// ---- row <-> registers -------------------------------------------------------
-template <int L, int NC, bool VEC>
-__device__ __forceinline__ void load_row(const double* __restrict__ p, int M, int j, double (&x)[2 * NC]) {
-#pragma unroll
-  for (int c = 0; c < NC; ++c) {
-    const int m0 = 2 * L * c + 2 * j;
-    if (VEC) {
-      if (m0 < M) {
-        const double2 v = *reinterpret_cast<const double2*>(p + m0);
-        x[2 * c] = v.x;
-        x[2 * c + 1] = v.y;
-      } else {
-        x[2 * c] = 0.0;
-        x[2 * c + 1] = 0.0;
-      }
-    } else {
-      x[2 * c] = (m0 < M) ? p[m0] : 0.0;
-      x[2 * c + 1] = (m0 + 1 < M) ? p[m0 + 1] : 0.0;
-    }
-  }
-}
-
-template <int L, int NC, bool VEC>
-__device__ __forceinline__ void store_row(double* __restrict__ p, int M, int j, const double (&x)[2 * NC]) {
-#pragma unroll
-  for (int c = 0; c < NC; ++c) {
-    const int m0 = 2 * L * c + 2 * j;
-    if (VEC) {
-      if (m0 < M) *reinterpret_cast<double2*>(p + m0) = make_double2(x[2 * c], x[2 * c + 1]);
-    } else {
-      if (m0 < M) p[m0] = x[2 * c];
-      if (m0 + 1 < M) p[m0 + 1] = x[2 * c + 1];
-    }
-  }
-}
-
-template <int L, int NC>
-__device__ __forceinline__ void lds_read_row(const double* __restrict__ ys, int j, double (&y)[2 * NC]) {
-#pragma unroll
-  for (int c = 0; c < NC; ++c) {
-    const double2 v = *reinterpret_cast<const double2*>(ys + 2 * L * c + 2 * j);
-    y[2 * c] = v.x;
-    y[2 * c + 1] = v.y;
-  }
-}
-
-// dot(x, ye) over the lane's slots with up to four independent FMA chains, then the group total
-template <int L, int NC>
-__device__ __forceinline__ double group_dot(const double (&x)[2 * NC], const double (&y)[2 * NC]) {
-  double s[4] = {0.0, 0.0, 0.0, 0.0};
-#pragma unroll
-  for (int c = 0; c < 2 * NC; ++c) s[c & 3] = __builtin_fma(x[c], y[c], s[c & 3]);
-  return group_sum<L>((s[0] + s[1]) + (s[2] + s[3]));
-}
-
-// sum over the lane's valid slots of (x - mean)^2, then the group total
-template <int L, int NC>
-__device__ __forceinline__ double group_centered_sumsq(const double (&x)[2 * NC], double mean, int M, int j) {
-  double s[4] = {0.0, 0.0, 0.0, 0.0};
-#pragma unroll
-  for (int c = 0; c < NC; ++c) {
-    const int m0 = 2 * L * c + 2 * j;
-    const double d0 = (m0 < M) ? (x[2 * c] - mean) : 0.0;
-    const double d1 = (m0 + 1 < M) ? (x[2 * c + 1] - mean) : 0.0;
-    s[(2 * c) & 3] = __builtin_fma(d0, d0, s[(2 * c) & 3]);
-    s[(2 * c + 1) & 3] = __builtin_fma(d1, d1, s[(2 * c + 1) & 3]);
-  }
-  return group_sum<L>((s[0] + s[1]) + (s[2] + s[3]));
-}
-
-// sum over ALL of the lane's slots of (x - mean)^2 (no masking), then the group total
-template <int L, int NC>
-__device__ __forceinline__ double group_sumsq_about(const double (&x)[2 * NC], double mean) {
-  double s[4] = {0.0, 0.0, 0.0, 0.0};
-#pragma unroll
-  for (int c = 0; c < 2 * NC; ++c) {
-    const double d = x[c] - mean;
-    s[c & 3] = __builtin_fma(d, d, s[c & 3]);
-  }
-  return group_sum<L>((s[0] + s[1]) + (s[2] + s[3]));
-}
-
-template <int L, int NC>
-__device__ __forceinline__ double group_rowsum(const double (&x)[2 * NC]) {
-  double s[4] = {0.0, 0.0, 0.0, 0.0};
-#pragma unroll
-  for (int c = 0; c < 2 * NC; ++c) s[c & 3] += x[c];
-  return group_sum<L>((s[0] + s[1]) + (s[2] + s[3]));
-}
 
 // ---------------------------------------------------------------------------
 // Sweep: rows x batch.
@@ -155,20 +46,20 @@ __global__ __launch_bounds__(kThreads) void k_sweep(const SweepArgs a) {
   if (VEC) {
     // 16-byte copies, four in flight per thread (the batch image is small and latency-bound)
     constexpr int S2 = S / 2;
-    const double2* src = reinterpret_cast<const double2*>(a.Ye);
     double2* dst = reinterpret_cast<double2*>(ye_s);
     const int M2 = M / 2;
     const int total = a.nb * S2;
 #pragma unroll 4
     for (int i = tid; i < total; i += kThreads) {
       const int k = i / S2, m2 = i - k * S2;
-      dst[i] = (m2 < M2) ? src[(size_t)k * M2 + m2] : make_double2(0.0, 0.0);
+      dst[i] = (m2 < M2) ? reinterpret_cast<const double2*>(a.Ye + (size_t)k * a.ye_stride)[m2]
+                         : make_double2(0.0, 0.0);
     }
   } else {
 #pragma unroll 4
     for (int i = tid; i < a.nb * S; i += kThreads) {
       const int k = i / S, m = i - k * S;
-      ye_s[i] = (m < M) ? a.Ye[(size_t)k * M + m] : 0.0;
+      ye_s[i] = (m < M) ? a.Ye[(size_t)k * a.ye_stride + m] : 0.0;
     }
   }
   for (int i = tid; i < a.nb * kCoefStride; i += kThreads) coef_s[i] = a.coef[i];
@@ -474,7 +365,7 @@ size_t diag_lds_bytes(int slots, int nb, int loc_mode) {
 hipError_t launch_sweep(const SweepArgs& a, hipStream_t s) {
   if (a.M < 2 || a.M > kMaxMembers || a.nb < 1 || a.nb > kMaxBatch) return hipErrorInvalidValue;
   if (a.nrows <= 0) return hipSuccess;
-  const bool vec = (a.M % 2 == 0) && aligned16(a.Xin) && aligned16(a.Xout) && aligned16(a.Ye);
+  const bool vec = (a.M % 2 == 0) && (a.ye_stride % 2 == 0) && aligned16(a.Xin) && aligned16(a.Xout) && aligned16(a.Ye);
   const int nch = sweep_slots(a.M) / 8;
   EFA_NCH_SWITCH(sweep4, a, vec, s)
 }

@@ -74,7 +74,10 @@ int efa_ctx_destroy(efa_ctx *ctx);
  * NULL restores the context's own stream */
 int efa_ctx_set_stream(efa_ctx *ctx, void *hip_stream);
 /* options: "obs_batch" (obs fused per sweep launch, 1..64, default 64),
- *          "path" (EFA_PATH_*), "threads_hint" (ignored) */
+ *          "path" (EFA_PATH_*), "timing" (0/1), "pipeline" (1: run Phase A as
+ *          one persistent launch when it applies, 0: per-batch kernels),
+ *          "spin_limit" (bound of the pipeline's in-kernel polls);
+ *          read-only: "phase_a_kind" (1 pipeline / 2 per-batch, last call) */
 int efa_ctx_set_option(efa_ctx *ctx, const char *key, long value);
 int efa_ctx_get_option(efa_ctx *ctx, const char *key, long *value);
 int efa_ctx_synchronize(efa_ctx *ctx);

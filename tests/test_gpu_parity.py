@@ -88,8 +88,33 @@ def test_host_abi_matches_reference_goldens(name, path, batch):
     assert np.array_equal(diag["assimilated"], g["assimilated"])
 
 
-class _StencilOb(object):
-    pass
+@pytest.mark.parametrize("name", GOLDEN_CASES)
+def test_phase_a_per_batch_kernels_and_pipeline_fallback(name):
+    """Phase A has two implementations (persistent pipeline / per-batch kernels); both must
+    match the reference, and a pipeline whose bounded polls expire must fall back cleanly."""
+    g = load_golden(name)
+    ctx = _ctx()
+    ctx.set_option("path", 1)
+    try:
+        for mode in ("pipeline", "batch", "expired"):
+            N, xbm, Xbp = prior_arrays(g)
+            ctx.set_option("pipeline", 0 if mode == "batch" else 1)
+            ctx.set_option("spin_limit", 1 if mode == "expired" else 4000000)
+            diag = ctx.ensrf_update_host(xbm, Xbp, N, g["ob_value"], g["ob_error"], g["ob_assim"],
+                                         **golden_kwargs(g))
+            kind = ctx.get_option("phase_a_kind")
+            if mode == "pipeline":
+                assert kind == 1
+            if mode == "batch":
+                assert kind == 2
+            assert_parity(xbm, g["xam"], "%s %s xam" % (name, mode))
+            for key in ("prior_mean", "prior_var", "post_mean", "post_var"):
+                assert_parity(diag[key], g[key], "%s %s %s" % (name, mode, key))
+            assert np.array_equal(diag["assimilated"], g["assimilated"])
+    finally:
+        ctx.set_option("pipeline", 1)
+        ctx.set_option("spin_limit", 4000000)
+        ctx.set_option("path", 0)
 
 
 def _make_api_objects(g):
@@ -191,9 +216,10 @@ def _run_oracle(c):
     return xam, Xap, diag
 
 
-def _run_hip(c, path="auto", batch=32):
+def _run_hip(c, path="auto", batch=32, pipeline=1):
     ctx = _ctx()
     ctx.set_option("obs_batch", batch)
+    ctx.set_option("pipeline", pipeline)
     ctx.set_option("path", {"auto": 0, "sweep": 1, "transform": 2}[path])
     xbm, Xbp = orc.format_prior_state(c["X"], c["HX"])
     kw = dict(loc_mode=0)
@@ -203,6 +229,7 @@ def _run_hip(c, path="auto", batch=32):
     diag = ctx.ensrf_update_host(xbm, Xbp, c["N"], c["val"], c["err"], c["asm"], **kw)
     ctx.set_option("path", 0)
     ctx.set_option("obs_batch", 64)
+    ctx.set_option("pipeline", 1)
     return xbm, Xbp, diag
 
 
@@ -219,8 +246,8 @@ SHAPES = [
 def test_seeded_shapes_vs_oracle(N, M, P, loc):
     c = _random_case(100 + N + M + P, N, M, P, loc, ncol=(N // 4 if loc and N % 4 == 0 and N >= 1024 else None))
     xam, Xap, diag = _run_oracle(c)
-    for path in (("sweep", "auto") if not loc else ("sweep",)):
-        h_xam, h_Xap, h_diag = _run_hip(c, path=path)
+    for path, pipe in ((("sweep", 1), ("auto", 1), ("sweep", 0)) if not loc else (("sweep", 1), ("sweep", 0))):
+        h_xam, h_Xap, h_diag = _run_hip(c, path=path, pipeline=pipe)
         assert_parity(h_xam, xam, "xam %s" % path)
         assert_parity(h_Xap, Xap, "Xap %s" % path)
         for key in ("prior_mean", "prior_var", "post_mean", "post_var"):
