@@ -92,7 +92,7 @@ struct efa_ctx {
   bool have_transform = false;   // identity rows were carried: (T, w) valid
   std::vector<uint8_t> h_assim;  // host copy of ob_assim
   DevBuf Ye_rec, coef;           // [P][M], [P][4]
-  DevBuf traj, tw_mat, status;   // pipeline: trajectory records, GC obs-obs taper, status words
+  DevBuf traj, tw_mat, status, dbg;  // pipeline: trajectory records, GC obs-obs taper, status words, stamps
   const double* ye_ptr = nullptr;  // where Phase B reads the recorded ye rows
   long ye_stride = 0;
   int phase_a_kind = 0;          // 1 pipeline, 2 per-batch kernels
@@ -247,6 +247,12 @@ int obs_phase(efa_ctx* c, int M, long P, double* ym_dev, double* Yp_dev, const d
     pa.status = c->status.as<int>();
     pa.spin_limit = c->spin_limit;
     pa.debug = (int)c->pipe_debug;
+    pa.dbg = nullptr;
+    if (c->pipe_debug & 4) {
+      EFA_TRY(c->dbg.reserve((size_t)P * 8 * sizeof(unsigned long long)));
+      EFA_HIP(hipMemsetAsync(c->dbg.p, 0, (size_t)P * 8 * sizeof(unsigned long long), s));
+      pa.dbg = c->dbg.as<unsigned long long>();
+    }
     EFA_HIP(launch_pipeline(pa, s));
     int st[2] = {0, 0};
     EFA_HIP(hipMemcpyAsync(st, c->status.p, sizeof(st), hipMemcpyDeviceToHost, s));
@@ -257,8 +263,13 @@ int obs_phase(efa_ctx* c, int M, long P, double* ym_dev, double* Yp_dev, const d
       c->ye_stride = TS;
       c->phase_a_kind = 1;
     }
-    // else: a bounded spin expired (co-residency lost?).  The kernel wrote nothing back;
-    // fall through to the per-batch kernels on the untouched obs block.
+    else {
+      // a bounded spin expired (co-residency lost?): workgroups that had already finished may
+      // have written their rows back, so restore the obs block before the per-batch kernels
+      EFA_HIP(hipMemcpyAsync(Yw, Yp_dev, (size_t)P * M * sizeof(double), hipMemcpyDeviceToDevice, s));
+      EFA_HIP(hipMemcpyAsync(ymw, ym_dev, dP, hipMemcpyDeviceToDevice, s));
+      if (carry_T) EFA_HIP(launch_set_identity(M, Yw + (size_t)P * M, ymw + P, s));
+    }
   }
   if (!done_by_pipeline) {
     c->ye_ptr = c->Ye_rec.as<double>();
@@ -515,7 +526,7 @@ int efa_ctx_destroy(efa_ctx* c) {
   if (c->stream) (void)hipStreamSynchronize(c->stream);
   DevBuf* bufs[] = {&c->Ye_rec, &c->coef, &c->ob_val, &c->ob_err, &c->ob_asm, &c->ob_lat, &c->ob_lon, &c->ob_hw,
                     &c->d_prior_mean, &c->d_prior_var, &c->d_post_mean, &c->d_post_var, &c->d_assimilated,
-                    &c->Yw, &c->ymw, &c->traj, &c->tw_mat, &c->status, &c->W, &c->glat, &c->glon, &c->xm_ws, &c->h_xm, &c->h_Xp, &c->h_ym, &c->h_Yp};
+                    &c->Yw, &c->ymw, &c->traj, &c->tw_mat, &c->status, &c->dbg, &c->W, &c->glat, &c->glon, &c->xm_ws, &c->h_xm, &c->h_Xp, &c->h_ym, &c->h_Yp};
   for (DevBuf* b : bufs) b->release();
   for (int i = 0; i < 4; ++i)
     if (c->ev[i]) (void)hipEventDestroy(c->ev[i]);
@@ -563,6 +574,7 @@ int efa_ctx_get_option(efa_ctx* c, const char* key, long* value) {
   else if (!strcmp(key, "timing")) *value = c->timing;
   else if (!strcmp(key, "pipeline")) *value = c->use_pipeline;
   else if (!strcmp(key, "phase_a_kind")) *value = c->phase_a_kind;
+  else if (!strcmp(key, "pipe_dbg_addr")) *value = (long)reinterpret_cast<uintptr_t>(c->dbg.p);
   else if (!strcmp(key, "device")) *value = c->device;
   else return fail(EFA_ERR_INVALID, "unknown option '%s'", key);
   return EFA_OK;

@@ -79,7 +79,7 @@ constexpr int kTrajScalars = 8;  // mye, mean(ye), innov, rden, beta, active, pr
 inline int traj_pad(int M) { return 16 * ((M + 15) / 16); }             // 8 lanes x 2 doubles per chunk
 inline long traj_stride(int M) { return traj_pad(M) + kTrajScalars; }
 constexpr int kPipeRowsPerWG = 64;
-constexpr int kPipeMaxWGs = 256;  // one 512-thread workgroup per CU: all co-resident
+constexpr int kPipeMaxWGs = 256;  // one 576-thread workgroup per CU: all co-resident
 
 struct PipeArgs {
   double* Yp;   // [R][M] obs block (+ extra identity rows), in/out
@@ -101,6 +101,7 @@ struct PipeArgs {
   uint8_t* assimilated;
   int* status;          // [2]: [0] abort flag (in-kernel), [1] 0 ok / 1 timeout
   long spin_limit;
+  unsigned long long* dbg;  // diagnostic (debug & 4): [P][8] cycle stamps of the leader chain, else null
   int debug;  // diagnostic bits (single-workgroup timing runs only): 1 no global publication, 2 no prefetch
 };
 

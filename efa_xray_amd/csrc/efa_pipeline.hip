@@ -2,28 +2,41 @@
 // restricted to the P obs rows of the augmented state) in ONE launch.
 //
 // Why: the loop is serial in k (ob k+1's prior depends on ob k's update), so its time is
-// P x (latency of one step).  Launching a diag + a sweep kernel per 64-ob batch put two
-// kernel boundaries, a 53 KB LDS re-staging and a full re-read of the obs block on that
-// chain for every batch.  Here every workgroup keeps its 64 obs rows in registers for the
-// entire loop and the steps are chained inside the launch:
+// P x (latency of one step).  A diag + a sweep kernel per 64-ob batch puts two kernel
+// boundaries, a 53 KB LDS re-staging and a full re-read of the obs block on that chain for
+// every batch.  Here every workgroup keeps its 64 obs rows in registers for the entire loop
+// and the steps are chained inside the launch.
 //
-//  - workgroup b owns rows [64b, 64b+64) (8 lanes per row, 512 threads).  It is the LEADER
-//    for obs 64b..64b+63 and a FOLLOWER for every other ob;
-//  - the leader's group that owns ob k publishes ye_k and the scalar gain factors
-//    (a) into the workgroup's LDS ring -- its own waves continue after one barrier --
-//    (b) into the global trajectory record traj[k] with agent-scope 8-byte stores;
-//  - a follower's wave 0 keeps kPrefetch records in flight (agent-scope 8-byte loads,
-//    compiler-tracked so no wait sits on the loop), validates every element against the
-//    sentinel the record was pre-filled with, re-polls until complete, and hands the row
-//    to its workgroup through the LDS ring;
-//  - no flags, fences or ordering between elements are needed: each 8-byte granule is
-//    self-validating (MI355X_MICROARCH.md "R2 granule"), loads/stores are agent scope
-//    (per-XCD L2s are not coherent for plain accesses);
-//  - all workgroups are co-resident (grid <= 256 CUs, one 512-thread workgroup each);
-//    every spin is bounded and a global abort word makes all workgroups leave; the host
-//    then falls back to the per-batch kernels (the obs block is only written at the end).
+// Roles.  Workgroup b owns rows [64b, 64b+64): 8 compute waves (8 lanes per row; consecutive
+// obs live in DIFFERENT waves so the work of adjacent steps overlaps) + 1 loader wave.  The
+// workgroup is the LEADER for its own 64 obs and a FOLLOWER for every other ob.
 //
-// The trajectory records double as the Phase-B input (ye rows + coefficients).
+// Hand-off inside a workgroup: an LDS ring of records (ye row + 8 scalars) and two LDS
+// counters, ready_ye / ready_sc.  No workgroup barrier in the loop: waves spin on the
+// counters (LDS operations of one wave are performed in order, so "write data, then write
+// counter" / "read counter, then read data" needs no wait states beyond the poll itself).
+// ready_ye is raised before the scalar gain factors are finished so that the other waves'
+// dot products overlap the owner's rsq/rcp chain.  Ring slots are recycled only after every
+// compute wave has reported (prog[w]) that it consumed the slot's previous record.
+//
+// Hand-off between workgroups: the leader's records are also written to global memory with
+// agent-scope 8-byte stores; every element was pre-filled with a sentinel NaN payload, so a
+// follower's loader wave validates each granule on its own -- no flag, fence or ordering
+// (MI355X_MICROARCH.md "R2 granule"; agent scope because per-XCD L2s are not coherent).  The
+// loader polls 4 records per round trip and is the only wave that waits on global memory;
+// while its workgroup leads, the same wave forwards the finished records from the LDS ring
+// to global memory, so publication costs the serial chain nothing.
+//
+// The leader's serial chain per step: poll -> ye from LDS -> dot -> 3-step DPP butterfly ->
+// gain -> {FMA update -> publish ye} || {variance by a one-step recurrence -> rsq/rcp with
+// Newton refinement -> publish scalars}.  The variance of row k+1 after ob k is
+//     var' = var - 2 kb cov(y, ye_k) + kb^2 var_k,   cov = dot/M - mean(y) mean(ye_k)
+// from a FRESH two-pass variance that the row's owner computed one step earlier, off the
+// chain; if var' < 1% of var (cancellation) it is recomputed from the updated row.
+//
+// All workgroups are co-resident (grid <= 256, one 576-thread workgroup per CU); every
+// spin is bounded; a global abort word releases everyone; the kernel then writes nothing
+// back and the host re-runs Phase A with the per-batch kernels.
 #include "efa_device.h"
 #include "efa_internal.h"
 #include "efa_rows.h"
@@ -31,10 +44,11 @@
 namespace efa {
 namespace {
 
-constexpr int kPT = 512;      // threads per workgroup
-constexpr int PL = 8;         // lanes per row
-constexpr int kRing = 4;      // LDS ring slots
-constexpr int kPrefetch = 4;  // trajectory records in flight per follower
+constexpr int kCW = 8;                 // compute waves per workgroup
+constexpr int kPT = 64 * (kCW + 1);    // + one loader wave
+constexpr int PL = 8;                  // lanes per row
+constexpr int kRing = 16;              // LDS ring slots
+constexpr int kPoll = 4;               // records fetched per loader round trip
 
 typedef unsigned long long u64;
 
@@ -44,40 +58,181 @@ __device__ __forceinline__ u64 traj_load(const u64* p) {
 __device__ __forceinline__ void traj_store(u64* p, double v) {
   __hip_atomic_store(p, (u64)__double_as_longlong(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
-// workgroup barrier that waits for LDS traffic only: outstanding global loads (prefetch) and
-// stores (publication) must stay in flight across it (__syncthreads() would add vmcnt(0))
-__device__ __forceinline__ void lds_barrier() {
-  asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+// LDS control words: plain in-order LDS accesses + a compiler barrier (see header comment)
+__device__ __forceinline__ int ctl_load_lane(const int* p) {  // per-lane address
+  const int v = __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+  asm volatile("" ::: "memory");
+  return v;
 }
+// every lane reads the same word: hand the compiler a wave-uniform (SGPR) value so that the
+// spin / bail logic compiles to scalar branches instead of exec-mask bookkeeping
+__device__ __forceinline__ int ctl_load(const int* p) { return __builtin_amdgcn_readfirstlane(ctl_load_lane(p)); }
+// minimum over the 8 lanes of a row group (DPP, no LDS round trip), same value in all 8 lanes
+__device__ __forceinline__ int group8_min(int v) {
+  v = min(v, __builtin_amdgcn_mov_dpp(v, 0xB1, 0xF, 0xF, true));
+  v = min(v, __builtin_amdgcn_mov_dpp(v, 0x4E, 0xF, 0xF, true));
+  v = min(v, __builtin_amdgcn_mov_dpp(v, 0x141, 0xF, 0xF, true));
+  return v;
+}
+__device__ __forceinline__ void ctl_store(int* p, int v) {
+  asm volatile("" ::: "memory");
+  __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+__device__ __forceinline__ double fast_rsq(double a) {  // 1/sqrt(a), two Newton steps on v_rsq_f64
+  double q = __builtin_amdgcn_rsq(a);
+#pragma unroll
+  for (int it = 0; it < 2; ++it) {
+    const double e = __builtin_fma(-a * q, q, 1.0);
+    q = __builtin_fma(0.5 * q, e, q);
+  }
+  return q;
+}
+__device__ __forceinline__ double fast_rcp(double b) {  // 1/b, two Newton steps on v_rcp_f64
+  double r = __builtin_amdgcn_rcp(b);
+#pragma unroll
+  for (int it = 0; it < 2; ++it) {
+    const double e = __builtin_fma(-b, r, 1.0);
+    r = __builtin_fma(r, e, r);
+  }
+  return r;
+}
+
+enum { kReadyYe = 0, kBail = 1, kReadySc = 2, kFwd = 3, kProg = 4 };  // ctl[] indices; prog[w] = ctl[kProg+w]
 
 template <int NC>
 __global__ __launch_bounds__(kPT) void k_pipe(const PipeArgs a) {
-  constexpr int PAD = 16 * NC;          // ye slots of a record
+  constexpr int PAD = 16 * NC;  // ye slots of a record
   constexpr int TS = PAD + kTrajScalars;
-  constexpr int EPL = (TS + 63) / 64;   // record elements per lane of the loader wave
+  constexpr int EPL = (TS + 63) / 64;  // record elements per lane of the loader wave
   __shared__ __align__(16) double ring[kRing * TS];
-  __shared__ int bail;
+  __shared__ int ctl[16];
 
   const int tid = threadIdx.x;
-  const int wave = tid >> 6, lane = tid & 63;
-  const int j = tid & (PL - 1);
-  const int r = tid / PL;  // 0..63
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
   const int M = a.M;
   const long P = a.P, R = a.R;
   const long own0 = (long)blockIdx.x * kPipeRowsPerWG;
-  const long own1 = (own0 + kPipeRowsPerWG < P) ? own0 + kPipeRowsPerWG : P;  // owned obs [own0, own1)
-  const long row = own0 + r;
+  const long own1 = (own0 + kPipeRowsPerWG < P) ? own0 + kPipeRowsPerWG : (own0 < P ? P : own0);
+
+  if (tid < 16) ctl[tid] = (tid >= kProg) ? -1 : (tid == kFwd ? (int)(own0 - 1) : 0);
+  __syncthreads();
+
+  // =====================================================================================
+  // loader wave
+  // =====================================================================================
+  if (wave == kCW) {
+    long next = 0;
+    long spins_left = a.spin_limit;
+    bool failed = false;
+    while (next < P && !failed) {
+      if (next >= own0 && next < own1) {
+        // leader phase: the owners publish into the LDS ring only; this wave forwards each
+        // finished record to global memory (agent-scope granules) for the other workgroups
+        for (long f = own0; f < own1 && !failed; ++f) {
+          while (ctl_load(&ctl[kReadySc]) <= (int)f) {
+            if (--spins_left <= 0 || ctl_load(&ctl[kBail]) != 0) {
+              failed = true;
+              break;
+            }
+            __builtin_amdgcn_s_sleep(1);
+          }
+          if (failed) break;
+          const double* slot = ring + (size_t)(f % kRing) * TS;
+          u64* rec = a.traj + (size_t)f * TS;
+          if (!(a.debug & 1)) {
+#pragma unroll
+            for (int e = 0; e < EPL; ++e) {
+              const int idx = lane + 64 * e;
+              if (idx < TS) traj_store(rec + idx, slot[idx]);
+            }
+          }
+          if (lane == 0) ctl_store(&ctl[kFwd], (int)f);
+        }
+        next = own1;
+        continue;
+      }
+      const long limit = (next < own0) ? ((own0 < P) ? own0 : P) : P;
+      const int nrec = (int)((limit - next < kPoll) ? (limit - next) : kPoll);
+      u64 v[kPoll][EPL];
+#pragma unroll
+      for (int d = 0; d < kPoll; ++d) {
+        const long kk = next + ((d < nrec) ? d : nrec - 1);
+        const u64* rec = a.traj + (size_t)kk * TS;
+#pragma unroll
+        for (int e = 0; e < EPL; ++e) {
+          const int idx = lane + 64 * e;
+          v[d][e] = traj_load(rec + (idx < TS ? idx : TS - 1));
+        }
+      }
+      int cnt = 0;
+#pragma unroll
+      for (int d = 0; d < kPoll; ++d) {
+        bool ok = true;
+#pragma unroll
+        for (int e = 0; e < EPL; ++e) ok = ok && (v[d][e] != kTrajSentinel);
+        if (cnt == d && d < nrec && __all(ok)) cnt = d + 1;
+      }
+      if (cnt == 0) {
+        if (--spins_left <= 0 || __hip_atomic_load(a.status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0)
+          failed = true;
+        __builtin_amdgcn_s_sleep(2);
+        continue;
+      }
+      // ring slots may be recycled only when every compute wave consumed their old record
+      const long need = next + cnt - 1 - kRing;  // all prog[w] must be >= need
+      if (need >= 0) {
+        for (;;) {
+          const int mn = __builtin_amdgcn_readfirstlane(group8_min(ctl_load_lane(&ctl[kProg + (lane & 7)])));
+          if (mn >= (int)need) break;
+          if (--spins_left <= 0) {
+            failed = true;
+            break;
+          }
+        }
+        if (failed) break;
+      }
+#pragma unroll
+      for (int d = 0; d < kPoll; ++d) {
+        if (d < cnt) {
+          double* slot = ring + (size_t)((next + d) % kRing) * TS;
+#pragma unroll
+          for (int e = 0; e < EPL; ++e) {
+            const int idx = lane + 64 * e;
+            if (idx < TS) slot[idx] = __longlong_as_double((long long)v[d][e]);
+          }
+        }
+      }
+      next += cnt;
+      if (lane == 0) {
+        ctl_store(&ctl[kReadySc], (int)next);
+        ctl_store(&ctl[kReadyYe], (int)next);
+      }
+    }
+    if (failed && lane == 0) {
+      __hip_atomic_store(a.status, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_store(a.status + 1, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      ctl_store(&ctl[kBail], 1);
+    }
+    return;
+  }
+
+  // =====================================================================================
+  // compute waves
+  // =====================================================================================
+  const int j = lane & (PL - 1);
+  const int grp = lane >> 3;
+  const int i_loc = wave + kCW * grp;  // local row / ob index 0..63: consecutive obs in different waves
+  const long row = own0 + i_loc;
   const bool live = row < R;
   const bool is_ob = row < P;
   const double rM1 = 1.0 / (double)(M - 1);
   const double dM = (double)M;
   const double invM = 1.0 / dM;
+  const double padc = (double)(PAD - M);
   const bool vec = (M % 2 == 0);
 
-  if (tid == 0) bail = 0;
-
   double x[2 * NC];
-  double xm = 0.0, my_val = 0.0, my_err = 1.0;
+  double xm = 0.0, my_val = 0.0, my_err = 1.0, my_sqrt_err = 1.0;
   bool my_asm = false;
   if (live) {
     if (vec) load_row<PL, NC, true>(a.Yp + (size_t)row * M, M, j, x);
@@ -86,6 +241,7 @@ __global__ __launch_bounds__(kPT) void k_pipe(const PipeArgs a) {
     if (is_ob) {
       my_val = a.ob_value[row];
       my_err = a.ob_error[row];
+      my_sqrt_err = sqrt(my_err);
       my_asm = a.ob_assim[row] != 0;
     }
   } else {
@@ -93,32 +249,40 @@ __global__ __launch_bounds__(kPT) void k_pipe(const PipeArgs a) {
     for (int c = 0; c < 2 * NC; ++c) x[c] = 0.0;
   }
   double rmean = group_rowsum<PL, NC>(x) / dM;
+  // fresh two-pass variance of the row as it stands (np.var, ddof = 0, ensrf.py:69)
+  auto fresh_var = [&]() {
+    return (group_sumsq_about<PL, NC>(x, rmean) - padc * (rmean * rmean)) * invM;
+  };
+  double vfresh = fresh_var();
 
   double o_prior_mean = 0.0, o_prior_var = 0.0, o_innov = 0.0, o_rden = 0.0, o_beta = 0.0;
   double o_post_mean = 0.0, o_post_var = 0.0;
   bool o_done = false;
+  long spins_left = a.spin_limit;
+  bool bailed = false;
+  auto give_up = [&]() {  // a bounded spin expired: release every workgroup, report to the host
+    __hip_atomic_store(a.status, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(a.status + 1, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    ctl_store(&ctl[kBail], 1);
+  };
 
-  // publish(k): by the 8 lanes that own row k, whose row is current through ob k-1
-  auto publish = [&](long k) {
-    double* slot = ring + (size_t)(k % kRing) * TS;
-    u64* rec = a.traj + (size_t)k * TS;
+  // Gain factors of the row as a prospective observation (ensrf.py:85,91,135), with
+  // q = 1/sqrt(kdenom): rden = q^2, beta = 1/(1 + sqrt(err/kdenom)) = 1/(1 + sqrt(err) q).
+  // Executed by every lane of the chain wave (uniform code); only the publishing group stores.
+  auto write_record = [&](long kn, double varye, bool pub) {
+    double* slot = ring + (size_t)(kn % kRing) * TS;
+    if (pub) {
 #pragma unroll
-    for (int c = 0; c < NC; ++c) {
-      const int m0 = 2 * PL * c + 2 * j;
-      *reinterpret_cast<double2*>(slot + m0) = make_double2(x[2 * c], x[2 * c + 1]);
-      if (!(a.debug & 1)) {
-        traj_store(rec + m0, x[2 * c]);
-        traj_store(rec + m0 + 1, x[2 * c + 1]);
-      }
+      for (int c = 0; c < NC; ++c)
+        *reinterpret_cast<double2*>(slot + 2 * PL * c + 2 * j) = make_double2(x[2 * c], x[2 * c + 1]);
+      if (j == 0) ctl_store(&ctl[kReadyYe], (int)(kn + 1));
     }
-    // np.var, ddof=0 (ensrf.py:69); padding slots hold 0 and add mean^2 each: remove it
-    const double ss = group_sumsq_about<PL, NC>(x, rmean) - (double)(PAD - M) * (rmean * rmean);
-    const double varye = ss * invM;
-    const double innov = my_val - xm;                       // :85
-    const double kdenom = varye + my_err;                   // :91
-    const double rden = 1.0 / kdenom;
-    const double beta = 1.0 / (1.0 + sqrt(my_err * rden));  // :135
-    double sv;  // lane j writes scalar j of the record
+    const double innov = my_val - xm;
+    const double kdenom = varye + my_err;
+    const double q = fast_rsq(kdenom);
+    const double rden = q * q;
+    const double beta = fast_rcp(1.0 + my_sqrt_err * q);
+    double sv;
     switch (j) {
       case 0: sv = xm; break;
       case 1: sv = rmean; break;
@@ -129,31 +293,36 @@ __global__ __launch_bounds__(kPT) void k_pipe(const PipeArgs a) {
       case 6: sv = varye; break;
       default: sv = 0.0; break;
     }
-    slot[PAD + j] = sv;
-    if (!(a.debug & 1)) traj_store(rec + PAD + j, sv);
-    o_prior_mean = xm;    // :66
-    o_prior_var = varye;  // :70
-    o_innov = innov;
-    o_rden = rden;
-    o_beta = beta;
-  };
-
-  // ---- loader state (wave 0): kPrefetch records in flight ------------------------------
-  u64 pend[kPrefetch][EPL];
-  auto issue = [&](long k, u64 (&dst)[EPL]) {
-    const long kk = (k < P) ? k : P - 1;  // clamp: harmless re-read at the tail
-    const u64* rec = a.traj + (size_t)kk * TS;
-#pragma unroll
-    for (int e = 0; e < EPL; ++e) {
-      const int idx = lane + 64 * e;
-      dst[e] = traj_load(rec + (idx < TS ? idx : TS - 1));
+    if (pub) {
+      slot[PAD + j] = sv;
+      if (j == 0) ctl_store(&ctl[kReadySc], (int)(kn + 1));
+      o_prior_mean = xm;    // :66
+      o_prior_var = varye;  // :70
+      o_innov = innov;
+      o_rden = rden;
+      o_beta = beta;
     }
   };
-  if (wave == 0) {
-#pragma unroll
-    for (int d = 0; d < kPrefetch; ++d) issue(d, pend[d]);
-  }
-  if (own0 == 0 && r == 0 && P > 0) publish(0);
+  // wave-uniform wait until the ring slot of record kn may be recycled: every compute wave
+  // consumed, and the forwarder forwarded, record kn - kRing
+  auto wait_slot_free = [&](long kn) {
+    for (;;) {
+      const int mn = __builtin_amdgcn_readfirstlane(
+          group8_min(min(ctl_load_lane(&ctl[kProg + j]), ctl_load_lane(&ctl[kFwd]))));
+      if (mn >= (int)(kn - kRing)) return;
+      if (ctl_load(&ctl[kBail]) != 0) {
+        bailed = true;
+        return;
+      }
+      if (--spins_left <= 0) {
+        give_up();
+        bailed = true;
+        return;
+      }
+    }
+  };
+
+  if (own0 == 0 && wave == 0 && P > 0) write_record(0, vfresh, i_loc == 0);
 
   // GC taper of ob k against this lane's row, prefetched two obs ahead
   double wq0 = 1.0, wq1 = 1.0;
@@ -163,78 +332,97 @@ __global__ __launch_bounds__(kPT) void k_pipe(const PipeArgs a) {
     wq1 = (P > 1) ? a.tw[(size_t)1 * R + row] : 1.0;
   }
 
-  long spins_left = a.spin_limit;
-  for (long k = 0; k < P; ++k) {
-    const bool mine = (k >= own0) && (k < own1);
-    double* slot = ring + (size_t)(k % kRing) * TS;
-    if (wave == 0) {
-      u64 cur[EPL];
-#pragma unroll
-      for (int e = 0; e < EPL; ++e) cur[e] = pend[0][e];
-#pragma unroll
-      for (int d = 0; d + 1 < kPrefetch; ++d)
-#pragma unroll
-        for (int e = 0; e < EPL; ++e) pend[d][e] = pend[d + 1][e];
-      if (!(a.debug & 2)) issue(k + kPrefetch, pend[kPrefetch - 1]);
-      if (!mine) {
-        bool ok = true;
-#pragma unroll
-        for (int e = 0; e < EPL; ++e) ok = ok && (cur[e] != kTrajSentinel);
-        while (!__all(ok)) {  // not yet published: re-poll (bounded)
-          if (--spins_left <= 0 || __hip_atomic_load(a.status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) {
-            if (lane == 0) {
-              __hip_atomic_store(a.status, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-              bail = 1;
-            }
-            break;
-          }
-          __builtin_amdgcn_s_sleep(2);
-          issue(k, cur);
-          ok = true;
-#pragma unroll
-          for (int e = 0; e < EPL; ++e) ok = ok && (cur[e] != kTrajSentinel);
-        }
-#pragma unroll
-        for (int e = 0; e < EPL; ++e) {
-          const int idx = lane + 64 * e;
-          if (idx < TS) slot[idx] = __longlong_as_double((long long)cur[e]);
-        }
+#define EFA_STAMP(i)                                                                     \
+  do {                                                                                   \
+    if (a.dbg != nullptr && pub && j == 0) a.dbg[(size_t)k * 8 + (i)] = __builtin_amdgcn_s_memtime(); \
+  } while (0)
+  for (long k = 0; k < P && !bailed; ++k) {
+    const double* slot = ring + (size_t)(k % kRing) * TS;
+    const long kn = k + 1, k2 = k + 2;
+    // wave-uniform roles: the wave holding the owner of ob k+1 carries this step's serial chain;
+    // the wave holding the owner of ob k+2 refreshes that row's variance off the chain
+    const bool chain_wave = (kn >= own0) && (kn < own1) && ((int)((kn - own0) & (kCW - 1)) == wave);
+    const bool fresh_wave = (k2 >= own0) && (k2 < own1) && ((int)((k2 - own0) & (kCW - 1)) == wave);
+    const bool pub = chain_wave && (i_loc == (int)(kn - own0));
+    if (chain_wave) __builtin_amdgcn_s_setprio(3);
+    else __builtin_amdgcn_s_setprio(0);
+    EFA_STAMP(0);
+    while (ctl_load(&ctl[kReadyYe]) <= (int)k) {
+      if (ctl_load(&ctl[kBail]) != 0) {
+        bailed = true;
+        break;
       }
+      if (--spins_left <= 0) {
+        give_up();
+        bailed = true;
+        break;
+      }
+      if (!chain_wave) __builtin_amdgcn_s_sleep(1);  // do not steal issue slots from the working waves
     }
-    lds_barrier();
-    if (bail) break;
-
-    const bool active = slot[PAD + 5] != 0.0;  // uniform
+    if (bailed) break;
+    EFA_STAMP(1);
+    double y[2 * NC];
+    lds_read_row<PL, NC>(slot, j, y);
     const double w = wq0;
     wq0 = wq1;
     if (use_tw) wq1 = a.tw[(size_t)((k + 2 < P) ? k + 2 : P - 1) * R + row];
+    const double dot = group_dot<PL, NC>(x, y);
+    EFA_STAMP(2);
+    while (ctl_load(&ctl[kReadySc]) <= (int)k) {
+      if (ctl_load(&ctl[kBail]) != 0) {
+        bailed = true;
+        break;
+      }
+      if (--spins_left <= 0) {
+        give_up();
+        bailed = true;
+        break;
+      }
+      if (!chain_wave) __builtin_amdgcn_s_sleep(1);
+    }
+    if (bailed) break;
+    const double2 s01 = *reinterpret_cast<const double2*>(slot + PAD);      // mye, mean(ye)
+    const double2 s23 = *reinterpret_cast<const double2*>(slot + PAD + 2);  // innov, rden
+    const double2 s45 = *reinterpret_cast<const double2*>(slot + PAD + 4);  // beta, active
+    const double var_k = slot[PAD + 6];
+    if (lane == 0) ctl_store(&ctl[kProg + wave], (int)k);  // record k consumed by this wave
+    EFA_STAMP(3);
+    const bool active = __builtin_amdgcn_readfirstlane((int)(s45.y != 0.0)) != 0;  // wave-uniform
+    double var_next = vfresh;          // variance of this row after ob k (meaningful for the publisher)
     if (active) {
-      double y[2 * NC];
-      lds_read_row<PL, NC>(slot, j, y);
-      const double dot = group_dot<PL, NC>(x, y);
-      double kc = dot * rM1;                      // :95
-      if (a.loc_mode != 0) kc = (live ? w : 0.0) * kc;  // :115
-      const double km = kc * slot[PAD + 3];       // :119
-      xm = xm + km * slot[PAD + 2];               // :130
-      const double kb = slot[PAD + 4] * km;       // :136
-      rmean = __builtin_fma(-kb, slot[PAD + 1], rmean);
+      double kc = dot * rM1;                                // :95
+      if (a.loc_mode != 0) kc = (live ? w : 0.0) * kc;      // :115
+      const double km = kc * s23.y;                         // :119
+      xm = xm + km * s23.x;                                 // :130
+      const double kb = s45.x * km;                         // :136
+      // one-step variance recurrence from the fresh value (see header)
+      const double cov = __builtin_fma(dot, invM, -(rmean * s01.y));
+      var_next = __builtin_fma(kb * kb, var_k, __builtin_fma(-2.0 * kb, cov, vfresh));
+      rmean = __builtin_fma(-kb, s01.y, rmean);
 #pragma unroll
       for (int c = 0; c < 2 * NC; ++c) x[c] = __builtin_fma(-kb, y[c], x[c]);  // :141
-      if (mine && r == (int)(k - own0)) {
+      if (k >= own0 && k < own1 && i_loc == (int)(k - own0)) {
         const double f = 1.0 - kb;  // the ob's own row was scaled by (1 - kb)  (:144-149)
         o_post_var = (f * f) * o_prior_var;
         o_post_mean = xm;
         o_done = true;
       }
     }
-    const long kn = k + 1;
-    if (kn >= own0 && kn < own1 && r == (int)(kn - own0)) publish(kn);
+    EFA_STAMP(4);
+    if (chain_wave) {
+      if (__any(pub && active && !(var_next > 0.01 * vfresh))) var_next = fresh_var();  // cancellation guard
+      if (kn >= kRing) wait_slot_free(kn);
+      if (bailed) break;
+      write_record(kn, var_next, pub);
+    }
+    EFA_STAMP(5);
+    if (fresh_wave) vfresh = fresh_var();  // off the chain (uniform over the wave)
+    EFA_STAMP(6);
   }
+#undef EFA_STAMP
+  __builtin_amdgcn_s_setprio(0);
 
-  if (bail) {
-    if (tid == 0) a.status[1] = 1;
-    return;  // nothing written back: the host re-runs Phase A with the per-batch kernels
-  }
+  if (bailed) return;  // nothing written back: the host re-runs Phase A with the per-batch kernels
   if (live) {
     if (vec) store_row<PL, NC, true>(a.Yp + (size_t)row * M, M, j, x);
     else store_row<PL, NC, false>(a.Yp + (size_t)row * M, M, j, x);
@@ -286,7 +474,7 @@ hipError_t pipe_launch(const PipeArgs& a, hipStream_t s) {
 }  // namespace
 
 bool pipeline_supported(int M, long R) {
-  return M >= 2 && M <= kMaxMembers && R > 0 && (R + kPipeRowsPerWG - 1) / kPipeRowsPerWG <= kPipeMaxWGs;
+  return M >= 2 && M <= 128 && R > 0 && (R + kPipeRowsPerWG - 1) / kPipeRowsPerWG <= kPipeMaxWGs;
 }
 
 hipError_t launch_pipeline(const PipeArgs& a, hipStream_t s) {
@@ -300,14 +488,6 @@ hipError_t launch_pipeline(const PipeArgs& a, hipStream_t s) {
     case 6: return pipe_launch<6>(a, s);
     case 7: return pipe_launch<7>(a, s);
     case 8: return pipe_launch<8>(a, s);
-    case 9: return pipe_launch<9>(a, s);
-    case 10: return pipe_launch<10>(a, s);
-    case 11: return pipe_launch<11>(a, s);
-    case 12: return pipe_launch<12>(a, s);
-    case 13: return pipe_launch<13>(a, s);
-    case 14: return pipe_launch<14>(a, s);
-    case 15: return pipe_launch<15>(a, s);
-    case 16: return pipe_launch<16>(a, s);
     default: return hipErrorInvalidValue;
   }
 }
