@@ -132,7 +132,7 @@ long effective_batch(const efa_ctx* c, int M) {
   // diag kernel's ring (ye rows + scalars + the GC taper matrix) must fit one CU's 160 KiB.
   const long s4 = sweep_slots(M), s16 = 32L * ((M + 31) / 32);
   const long per_ob = ((s4 > s16 ? s4 : s16) + kCoefStride) * (long)sizeof(double);
-  while (b > 1 && (b * per_ob > 150L * 1024 || (long)diag_lds_bytes((int)s4, (int)b, 1) > 150L * 1024)) --b;
+  while (b > 1 && (b * per_ob + 64L * kMaxBatch * 8 > 150L * 1024 || (long)diag_lds_bytes((int)s4, (int)b, 1) > 150L * 1024)) --b;
   return b;
 }
 

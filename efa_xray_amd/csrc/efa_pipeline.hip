@@ -47,7 +47,8 @@ namespace {
 constexpr int kCW = 8;                 // compute waves per workgroup
 constexpr int kPT = 64 * (kCW + 1);    // + one loader wave
 constexpr int PL = 8;                  // lanes per row
-constexpr int kRing = 16;              // LDS ring slots
+constexpr int kRing = 32;              // LDS ring slots
+constexpr int kGuardEvery = 8;         // the slot-recycling guard is evaluated once per this many records
 constexpr int kPoll = 4;               // records fetched per loader round trip
 
 typedef unsigned long long u64;
@@ -411,7 +412,8 @@ __global__ __launch_bounds__(kPT) void k_pipe(const PipeArgs a) {
     EFA_STAMP(4);
     if (chain_wave) {
       if (__any(pub && active && !(var_next > 0.01 * vfresh))) var_next = fresh_var();  // cancellation guard
-      if (kn >= kRing) wait_slot_free(kn);
+      // recycling guard, amortised: once per kGuardEvery records, for that many records ahead
+      if ((kn & (kGuardEvery - 1)) == 0 && kn + kGuardEvery > kRing) wait_slot_free(kn + kGuardEvery - 1);
       if (bailed) break;
       write_record(kn, var_next, pub);
     }

@@ -40,6 +40,7 @@ __global__ __launch_bounds__(kThreads) void k_sweep(const SweepArgs a) {
   constexpr int kRowsPerBlock = kThreads / L;
   double* ye_s = smem;
   double* coef_s = smem + (size_t)a.nb * S;
+  double* wtab = coef_s + (size_t)a.nb * kCoefStride;  // [rows per block][kMaxBatch], table mode only
   const int tid = threadIdx.x;
   const int M = a.M;
 
@@ -69,6 +70,9 @@ __global__ __launch_bounds__(kThreads) void k_sweep(const SweepArgs a) {
   const int r = tid / L;
   const double rM1 = 1.0 / (double)(M - 1);
   const long nblocks = (a.nrows + kRowsPerBlock - 1) / kRowsPerBlock;
+  unsigned long long assim_mask = 0ull;  // obs of the batch that are assimilated (wave-uniform)
+  for (int k = 0; k < a.nb; ++k)
+    if (__builtin_amdgcn_readfirstlane((int)(coef_s[k * kCoefStride + 3] != 0.0))) assim_mask |= 1ull << k;
 
   for (long blk = blockIdx.x; blk < nblocks; blk += gridDim.x) {
     const long row = blk * kRowsPerBlock + r;
@@ -82,35 +86,59 @@ __global__ __launch_bounds__(kThreads) void k_sweep(const SweepArgs a) {
 #pragma unroll
       for (int c = 0; c < 2 * NC; ++c) x[c] = 0.0;
     }
-    long col = 0;
-    double rlat = 0.0, rlon = 0.0;
-    const bool obs_taper = (a.taper_mode == kTaperObs) && live && (row < a.taper_rows);
-    if (a.taper_mode == kTaperTable) col = live ? (row % a.ncol) : 0;
-    if (obs_taper) {
-      rlat = a.row_lat[row];
-      rlon = a.row_lon[row];
-    }
-
-    for (int k = 0; k < a.nb; ++k) {
+    // one observation applied to the row held in registers
+    auto apply = [&](int k, double w) {
       const double* ck = coef_s + k * kCoefStride;
-      if (ck[3] == 0.0) continue;  // not assimilated (uniform)
-      double w = 1.0;
-      if (a.taper_mode == kTaperTable) {
-        w = live ? a.W[(size_t)k * a.ncol + col] : 0.0;
-        if (__ballot(w != 0.0) == 0ull) continue;  // whole wave outside 2*halfwidth
-      } else if (a.taper_mode == kTaperObs) {
-        if (obs_taper) w = gaspari_cohn(haversine_km(a.ob_lat[k], a.ob_lon[k], rlat, rlon), a.ob_hw[k]);
-      }
       double y[2 * NC];
       lds_read_row<L, NC>(ye_s + k * S, j, y);
       const double dot = group_dot<L, NC>(x, y);
-      double kc = dot * rM1;   // kcov = dot/(Nens-1)
-      kc = w * kc;             // localisation
+      double kc = dot * rM1;         // kcov = dot/(Nens-1)
+      kc = w * kc;                   // localisation
       const double km = kc * ck[1];  // kmat = kcov/kdenom
-      xm = xm + km * ck[0];    // xam = xbm + kmat*innov
+      xm = xm + km * ck[0];          // xam = xbm + kmat*innov
       const double kb = ck[2] * km;  // beta*kmat
 #pragma unroll
       for (int c = 0; c < 2 * NC; ++c) x[c] = __builtin_fma(-kb, y[c], x[c]);
+    };
+
+    if (a.taper_mode == kTaperTable) {
+      // All nb taper values of this row are fetched up front (16 independent loads per lane,
+      // lane j takes obs k = j mod 4) and parked in LDS, and the wave's set of obs with any
+      // non-zero weight is reduced to one 64-bit mask: the k loop then visits only those obs
+      // and never waits on a dependent global load.  Rows beyond 2*halfwidth of every ob of the
+      // batch cost one load burst and no arithmetic (F3: zero weight == bit-unchanged row).
+      const long col = live ? (row % a.ncol) : 0;
+      double* wrow = wtab + (size_t)r * kMaxBatch;
+      unsigned long long act = 0ull;
+#pragma unroll
+      for (int i = 0; i < kMaxBatch / L; ++i) {
+        const int kk = L * i + j;
+        const double wv = (live && kk < a.nb) ? a.W[(size_t)kk * a.ncol + col] : 0.0;
+        wrow[kk] = wv;
+        const unsigned long long bal = __ballot(wv != 0.0);
+#pragma unroll
+        for (int qq = 0; qq < L; ++qq)
+          if (bal & (0x1111111111111111ull << qq)) act |= 1ull << (L * i + qq);
+      }
+      act &= assim_mask;
+      while (act) {
+        const int k = __builtin_ctzll(act);
+        act &= act - 1;
+        apply(k, wrow[k]);
+      }
+    } else {
+      double rlat = 0.0, rlon = 0.0;
+      const bool obs_taper = (a.taper_mode == kTaperObs) && live && (row < a.taper_rows);
+      if (obs_taper) {
+        rlat = a.row_lat[row];
+        rlon = a.row_lon[row];
+      }
+      for (int k = 0; k < a.nb; ++k) {
+        if (!((assim_mask >> k) & 1ull)) continue;  // not assimilated (uniform)
+        double w = 1.0;
+        if (obs_taper) w = gaspari_cohn(haversine_km(a.ob_lat[k], a.ob_lon[k], rlat, rlon), a.ob_hw[k]);
+        apply(k, w);
+      }
     }
 
     if (live) {
@@ -286,7 +314,8 @@ template <int L, int NC>
 hipError_t sweep_launch(const SweepArgs& a, bool vec, hipStream_t s) {
   constexpr int kRowsPerBlock = kThreads / L;
   const long nblocks = (a.nrows + kRowsPerBlock - 1) / kRowsPerBlock;
-  const size_t lds = ((size_t)a.nb * 2 * L * NC + (size_t)a.nb * kCoefStride) * sizeof(double);
+  const size_t lds = ((size_t)a.nb * 2 * L * NC + (size_t)a.nb * kCoefStride +
+                      (a.taper_mode == kTaperTable ? (size_t)kRowsPerBlock * kMaxBatch : 0)) * sizeof(double);
   long grid = nblocks < 256L * 8 ? nblocks : 256L * 8;
   if (grid < 1) grid = 1;
   if (lds > 64 * 1024) {

@@ -102,6 +102,74 @@ __global__ __launch_bounds__(THREADS) void k_t(const double* __restrict__ Xin, d
   }
 }
 
+
+// ---- variant 2: column-tile outer loop, ACCS accumulators in flight, each tile stored as soon as done
+template <int THREADS, int ACCS, int STAGGER>
+__global__ __launch_bounds__(THREADS) void k_t2(const double* __restrict__ Xin, double* __restrict__ Xout,
+                                                const double* __restrict__ T, long nrows) {
+  extern __shared__ __align__(16) double Bs[];
+  const int tid = threadIdx.x;
+  for (int i = tid; i < 2 * NU * NT * 64; i += THREADS) {
+    const int l = i & 63, st = i >> 6, s = st % (2 * NU), t = st / (2 * NU), u = s >> 1, h = s & 1, g = l >> 4, n = l & 15;
+    const int m = 8 * u + 2 * g + h, j = 16 * t + n;
+    Bs[i] = (m < M && j < M) ? T[m * M + j] : 0.0;   // layout [t][s][lane]
+  }
+  __syncthreads();
+  const int lane = tid & 63, g = lane >> 4, n = lane & 15;
+  const long ntiles = (nrows + 15) / 16;
+  const long wave = (long)blockIdx.x * (THREADS / 64) + (tid >> 6);
+  const long nwaves = (long)gridDim.x * (THREADS / 64);
+  double a[2 * NU], an[2 * NU];
+  auto load = [&](long tile, double (&d)[2 * NU]) {
+    const double* p = Xin + (size_t)(tile * 16 + n) * M;
+#pragma unroll
+    for (int u = 0; u < NU; ++u) {
+      int m0 = 8 * u + 2 * g;
+      if (u == NU - 1) m0 = (m0 < M) ? m0 : M - 2;
+      const double2 v = *reinterpret_cast<const double2*>(p + m0);
+      d[2 * u] = v.x; d[2 * u + 1] = v.y;
+    }
+  };
+  if (STAGGER && (tid >> 6) >= (THREADS / 128)) __builtin_amdgcn_s_sleep(127);
+  long tile = wave;
+  if (tile < ntiles) load(tile, a);
+  const bool last_ok = (8 * (NU - 1) + 2 * g) < M;
+  while (tile < ntiles) {
+    const long next = tile + nwaves;
+    load(next < ntiles ? next : tile, an);
+    if (!last_ok) { a[2 * NU - 2] = 0; a[2 * NU - 1] = 0; }
+    const long r0 = tile * 16;
+#pragma unroll
+    for (int t0 = 0; t0 < NT; t0 += ACCS) {
+      v4f64 acc[ACCS];
+#pragma unroll
+      for (int q = 0; q < ACCS; ++q) acc[q] = (v4f64){0, 0, 0, 0};
+#pragma unroll
+      for (int s = 0; s < 2 * NU; ++s) {
+#pragma unroll
+        for (int q = 0; q < ACCS; ++q) {
+          if (t0 + q < NT) {
+            const double b = Bs[((size_t)(t0 + q) * (2 * NU) + s) * 64 + lane];
+            acc[q] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[s], b, acc[q], 0, 0, 0);
+          }
+        }
+        if ((s & 3) == 3) __builtin_amdgcn_sched_barrier(0);
+      }
+#pragma unroll
+      for (int q = 0; q < ACCS; ++q) {
+        const int col = 16 * (t0 + q) + n;
+        if (t0 + q < NT && col < M) {
+#pragma unroll
+          for (int v = 0; v < 4; ++v) Xout[(size_t)(r0 + 4 * v + g) * M + col] = acc[q][v];
+        }
+      }
+    }
+#pragma unroll
+    for (int c = 0; c < 2 * NU; ++c) a[c] = an[c];
+    tile = next;
+  }
+}
+
 template <typename K>
 float run(K kern, int threads, int grid, const double* X, double* Y, const double* T, long rows, const char* name) {
   const size_t lds = (size_t)2 * NU * NT * 64 * 8;
@@ -149,6 +217,14 @@ int main(int argc, char** argv) {
     printf("%-44s                       : %7.3f ms  (%6.0f GB/s r+w)\n", "float4-style copy (16B/lane)", ms, 16.0 * rows * M / ms / 1e6);
   }
   run(k_t<512, true, true, true, 0, 2>, 512, 256, X, Y, T, rows, "full (product structure)");
+  run(k_t2<512, 1, 0>, 512, 256, X, Y, T, rows, "t-outer, 1 acc");
+  run(k_t2<512, 2, 0>, 512, 256, X, Y, T, rows, "t-outer, 2 acc");
+  run(k_t2<512, 4, 0>, 512, 256, X, Y, T, rows, "t-outer, 4 acc");
+  run(k_t2<512, 2, 1>, 512, 256, X, Y, T, rows, "t-outer, 2 acc, staggered halves");
+  run(k_t2<768, 1, 0>, 768, 256, X, Y, T, rows, "t-outer, 1 acc, 768 thr");
+  run(k_t2<768, 2, 0>, 768, 256, X, Y, T, rows, "t-outer, 2 acc, 768 thr");
+  run(k_t2<1024, 1, 0>, 1024, 256, X, Y, T, rows, "t-outer, 1 acc, 1024 thr");
+  run(k_t2<1024, 2, 0>, 1024, 256, X, Y, T, rows, "t-outer, 2 acc, 1024 thr");
   run(k_t<512, true, true, false, 0, 2>, 512, 256, X, Y, T, rows, "no store");
   run(k_t<512, true, false, true, 0, 2>, 512, 256, X, Y, T, rows, "no mfma (load+store 8B)");
   run(k_t<512, true, false, true, 1, 2>, 512, 256, X, Y, T, rows, "no mfma (load+store 16B paired)");
