@@ -149,3 +149,21 @@ def test_observation_defaults_and_interpolate_stencil():
     assert np.allclose([got[r] for r in later], w_later * sw)
     assert o.estimate(st) is not None
     assert Observation(obtype="v0", time=1e9, lat=40, lon=240).estimate(st) is None
+
+
+def test_obs_statistics_table_columns():
+    from efa_xray_amd import Observation
+    from efa_xray_amd.postprocess.postprocess import obs_assimilation_statistics
+    st, arr, lat, lon = _state(5)
+    obs = [Observation(value=1.0, obtype="v0", time=3600.0, lat=40.1, lon=240.2, error=0.5, description="a"),
+           Observation(value=2.0, obtype="v1", time=3600.0, lat=45.0, lon=250.0, error=0.7, description="b")]
+    df = obs_assimilation_statistics(st, st, obs)
+    for col in ('validtime', 'flead', 'lat', 'lon', 'obtype', 'description', 'ob error', 'value', 'assimilated',
+                'prior mean', 'post mean', 'prior variance', 'post variance'):
+        assert col in df.columns
+    ye = obs[0].estimate(st)
+    assert abs(df['prior mean'][0] - ye.mean()) < 1e-15 and abs(df['post variance'][0] - ye.var()) < 1e-15
+    obs[0].prior_mean, obs[0].prior_var = 1.5, 2.5
+    obs[1].prior_mean, obs[1].prior_var, obs[1].post_mean, obs[1].post_var, obs[1].assimilated = 1.0, 2.0, 0.5, 1.0, True
+    df2 = obs_assimilation_statistics(st, st, obs, from_diagnostics=True)
+    assert df2['post mean'][1] == 0.5 and df2['post variance'][0] == 2.5
