@@ -76,6 +76,8 @@ SIGNATURES = {
                                         c_double_p, c_double_p, c_double_p, c_double_p, c_double_p,
                                         ctypes.c_long, ctypes.c_long,
                                         c_double_p, c_double_p, c_double_p, c_double_p, c_uint8_p]),
+    "efa_cov_contract_f32_dev": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_long, ctypes.c_int, ctypes.c_long,
+                                                ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]),
     "efa_last_timing": (ctypes.c_int, [ctypes.c_void_p, c_double_p, c_double_p,
                                        ctypes.POINTER(ctypes.c_long), ctypes.POINTER(ctypes.c_int)]),
     "efa_fill_synthetic_dev": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_long, ctypes.c_long, ctypes.c_int,
@@ -241,6 +243,8 @@ class Context(object):
             return None
         if isinstance(x, DeviceArray):
             return x.ptr
+        if isinstance(x, ctypes.c_void_p):
+            return x
         return ctypes.c_void_p(int(x))      # raw device address (e.g. torch data_ptr())
 
     def form_perts(self, rows, M, X, xm, Xp, scale=1.0):
@@ -355,6 +359,27 @@ class Context(object):
             _u8p(d["assimilated"])))
         d["assimilated"] = d["assimilated"].astype(bool)
         return d
+
+    def cov_contract_f32(self, N, M, P, Xbp_f32, Ye_f32, C_f32):
+        """C (N x P) = Xbp (N x M) . Ye^T (P x M), float32, device addresses."""
+        _check(self.lib, self.lib.efa_cov_contract_f32_dev(self.handle, N, M, P, self._addr(Xbp_f32),
+                                                           self._addr(Ye_f32), self._addr(C_f32)))
+
+    def malloc_bytes(self, nbytes):
+        ptr = ctypes.c_void_p()
+        _check(self.lib, self.lib.efa_malloc(self.handle, int(nbytes), ctypes.byref(ptr)))
+        return ptr
+
+    def free_bytes(self, ptr):
+        _check(self.lib, self.lib.efa_free(self.handle, ptr))
+
+    def h2d(self, dst_ptr, host):
+        host = np.ascontiguousarray(host)
+        _check(self.lib, self.lib.efa_memcpy_h2d(self.handle, dst_ptr, host.ctypes.data, host.nbytes))
+
+    def d2h(self, host_out, src_ptr):
+        assert host_out.flags["C_CONTIGUOUS"]
+        _check(self.lib, self.lib.efa_memcpy_d2h(self.handle, host_out.ctypes.data, src_ptr, host_out.nbytes))
 
     def last_timing(self):
         s = ctypes.c_double(0)

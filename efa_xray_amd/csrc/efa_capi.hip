@@ -537,7 +537,8 @@ int efa_ctx_destroy(efa_ctx* c) {
 
 int efa_ctx_set_stream(efa_ctx* c, void* hip_stream) {
   EFA_TRY(use(c));
-  c->stream = hip_stream ? reinterpret_cast<hipStream_t>(hip_stream) : c->own_stream;
+  // NULL is a valid handle: the device's legacy default stream (what torch uses unless told otherwise)
+  c->stream = reinterpret_cast<hipStream_t>(hip_stream);
   return EFA_OK;
 }
 
@@ -554,6 +555,8 @@ int efa_ctx_set_option(efa_ctx* c, const char* key, long value) {
     c->timing = value ? 1 : 0;
   } else if (!strcmp(key, "pipeline")) {
     c->use_pipeline = value ? 1 : 0;
+  } else if (!strcmp(key, "own_stream")) {
+    c->stream = c->own_stream;  // back to the context's private non-blocking stream
   } else if (!strcmp(key, "pipe_debug")) {
     c->pipe_debug = value;
   } else if (!strcmp(key, "spin_limit")) {
@@ -772,6 +775,19 @@ int efa_ensrf_update(efa_ctx* c, long A, long N, int M, long P, double* xbm, dou
     EFA_HIP(hipMemcpyAsync(Xbp + (size_t)N * M, c->h_Yp.p, (size_t)P * rowb, hipMemcpyDeviceToHost, s));
   }
   EFA_HIP(hipStreamSynchronize(s));
+  return EFA_OK;
+}
+
+int efa_cov_contract_f32_dev(efa_ctx* c, long N, int M, long P, const float* Xbp_f32_dev, const float* Ye_f32_dev,
+                             float* C_f32_dev) {
+  EFA_TRY(use(c));
+  if (N < 0 || P < 0 || M < 4 || (M & 3) != 0)
+    return fail(EFA_ERR_INVALID, "efa_cov_contract_f32_dev: need N,P >= 0 and M a positive multiple of 4 (M=%d)", M);
+  if (N == 0 || P == 0) return EFA_OK;
+  if (!Xbp_f32_dev || !Ye_f32_dev || !C_f32_dev) return fail(EFA_ERR_INVALID, "null pointer");
+  if ((reinterpret_cast<uintptr_t>(Xbp_f32_dev) & 15u) || (reinterpret_cast<uintptr_t>(Ye_f32_dev) & 15u))
+    return fail(EFA_ERR_INVALID, "operands must be 16-byte aligned");
+  EFA_HIP(efa::launch_contract_f32(N, M, P, Xbp_f32_dev, Ye_f32_dev, C_f32_dev, c->stream));
   return EFA_OK;
 }
 

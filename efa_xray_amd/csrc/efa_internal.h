@@ -144,5 +144,6 @@ hipError_t launch_forward_stencil(long rows, long row_offset, int M, const doubl
 hipError_t launch_fill_synthetic(long rows, long row_offset, int M, uint64_t seed, double sigma,
                                  double* X, hipStream_t s);
 hipError_t launch_set_identity(int M, double* T, double* w, hipStream_t s);
+hipError_t launch_contract_f32(long N, int M, long P, const float* X, const float* Ye, float* C, hipStream_t s);
 
 }  // namespace efa

@@ -70,8 +70,9 @@ int efa_device_count(int *count);
 /* create a context on HIP device `device_id` (must be gfx950) */
 int efa_ctx_create(int device_id, efa_ctx **out);
 int efa_ctx_destroy(efa_ctx *ctx);
-/* issue all work on the caller's hipStream_t (e.g. torch's current stream);
- * NULL restores the context's own stream */
+/* issue all work on the caller's hipStream_t (e.g. torch's current stream).
+ * NULL is the device's legacy default stream.  A new context uses a private
+ * non-blocking stream; efa_ctx_set_option(ctx, "own_stream", 1) returns to it. */
 int efa_ctx_set_stream(efa_ctx *ctx, void *hip_stream);
 /* options: "obs_batch" (obs fused per sweep launch, 1..64, default 64),
  *          "path" (EFA_PATH_*), "timing" (0/1), "pipeline" (1: run Phase A as
@@ -197,6 +198,16 @@ int efa_ensrf_update(efa_ctx *ctx, long A, long N, int M, long P, double *xbm,
                      const double *grid_lon, long ncol, long n_lead,
                      double *prior_mean, double *prior_var, double *post_mean,
                      double *post_var, uint8_t *assimilated);
+
+/* ---- configs[4]: batched-obs dense contraction, float32 --------------------
+ * C[i*P + k] = sum_m Xbp[i*M + m] * Ye[k*M + m]: the covariance numerators
+ * `np.dot(Xbp, ye.T)` of ensrf.py:95 for P recorded obs-space rows at once, as
+ * one (state x member).(member x obs) contraction on the matrix cores
+ * (v_mfma_f32_32x32x2_f32: exact f32 FMA chains).  All pointers are device
+ * memory; M must be a multiple of 4; divide by (M-1) for covariances. */
+int efa_cov_contract_f32_dev(efa_ctx *ctx, long N, int M, long P,
+                             const float *Xbp_f32_dev, const float *Ye_f32_dev,
+                             float *C_f32_dev);
 
 /* ---- measurement support --------------------------------------------------
  * Device time (ms) spent in the state-sweep kernels and in the obs-space

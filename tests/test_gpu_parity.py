@@ -438,3 +438,30 @@ def test_errors_are_loud():
         EnSRF(st, [ob], verbose=False, loc=True).update()
     with pytest.raises(ValueError):
         EnSRF(st, [ob], verbose=False, loc='GC').update()   # localize_radius is None
+
+
+@pytest.mark.parametrize("N,M,P", [(1, 4, 1), (130, 8, 70), (257, 128, 129), (1000, 100, 300), (4096, 128, 512)])
+def test_dense_contraction_f32_vs_float64(N, M, P):
+    """configs[4] path: fp32 MFMA contraction against a float64 evaluation, rtol 1e-4."""
+    ctx = _ctx()
+    rng = np.random.default_rng(N + M + P)
+    X = rng.standard_normal((N, M)).astype(np.float32)
+    Ye = rng.standard_normal((P, M)).astype(np.float32)
+    dX, dY, dC = ctx.malloc_bytes(X.nbytes), ctx.malloc_bytes(Ye.nbytes), ctx.malloc_bytes(N * P * 4)
+    try:
+        ctx.h2d(dX, X)
+        ctx.h2d(dY, Ye)
+        ctx.cov_contract_f32(N, M, P, dX, dY, dC)
+        C = np.empty((N, P), dtype=np.float32)
+        ctx.d2h(C, dC)
+    finally:
+        for p in (dX, dY, dC):
+            ctx.free_bytes(p)
+    ref = X.astype(np.float64) @ Ye.astype(np.float64).T
+    scale = np.abs(X.astype(np.float64)) @ np.abs(Ye.astype(np.float64)).T   # sum |a b|
+    assert np.all(np.abs(C - ref) <= 1e-4 * np.abs(ref) + 2e-6 * scale)
+    # exact f32 FMA chain in k order (the MFMA's documented numerics) for one row
+    chain = np.zeros(P, dtype=np.float32)
+    for m in range(M):
+        chain = (chain.astype(np.float64) + X[0, m].astype(np.float64) * Ye[:, m].astype(np.float64)).astype(np.float32)
+    assert np.allclose(C[0], chain, rtol=2e-6, atol=1e-6)
