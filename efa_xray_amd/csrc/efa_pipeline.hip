@@ -12,11 +12,12 @@
 // workgroup is the LEADER for its own 64 obs and a FOLLOWER for every other ob.
 //
 // Hand-off inside a workgroup: an LDS ring of records (ye row + 8 scalars) and two LDS
-// counters, ready_ye / ready_sc.  No workgroup barrier in the loop: waves spin on the
+// counter, ready.  No workgroup barrier in the loop: waves spin on the
 // counters (LDS operations of one wave are performed in order, so "write data, then write
 // counter" / "read counter, then read data" needs no wait states beyond the poll itself).
-// ready_ye is raised before the scalar gain factors are finished so that the other waves'
-// dot products overlap the owner's rsq/rcp chain.  Ring slots are recycled only after every
+// The owner starts the long scalar chain (rsq/rcp + Newton) in the same straight-line block as
+// the independent row update, so both are finished together and ONE counter publishes the whole
+// record: consumers fetch ye and the scalars in a single LDS round trip.  Ring slots are recycled only after every
 // compute wave has reported (prog[w]) that it consumed the slot's previous record.
 //
 // Hand-off between workgroups: the leader's records are also written to global memory with
@@ -130,7 +131,7 @@ __global__ __launch_bounds__(kPT) void k_pipe(const PipeArgs a) {
         // leader phase: the owners publish into the LDS ring only; this wave forwards each
         // finished record to global memory (agent-scope granules) for the other workgroups
         for (long f = own0; f < own1 && !failed; ++f) {
-          while (ctl_load(&ctl[kReadySc]) <= (int)f) {
+          while (ctl_load(&ctl[kReadyYe]) <= (int)f) {
             if (--spins_left <= 0 || ctl_load(&ctl[kBail]) != 0) {
               failed = true;
               break;
@@ -204,10 +205,7 @@ __global__ __launch_bounds__(kPT) void k_pipe(const PipeArgs a) {
         }
       }
       next += cnt;
-      if (lane == 0) {
-        ctl_store(&ctl[kReadySc], (int)next);
-        ctl_store(&ctl[kReadyYe], (int)next);
-      }
+      if (lane == 0) ctl_store(&ctl[kReadyYe], (int)next);
     }
     if (failed && lane == 0) {
       __hip_atomic_store(a.status, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -267,41 +265,49 @@ __global__ __launch_bounds__(kPT) void k_pipe(const PipeArgs a) {
     ctl_store(&ctl[kBail], 1);
   };
 
-  // Gain factors of the row as a prospective observation (ensrf.py:85,91,135), with
-  // q = 1/sqrt(kdenom): rden = q^2, beta = 1/(1 + sqrt(err/kdenom)) = 1/(1 + sqrt(err) q).
-  // Executed by every lane of the chain wave (uniform code); only the publishing group stores.
-  auto write_record = [&](long kn, double varye, bool pub) {
-    double* slot = ring + (size_t)(kn % kRing) * TS;
-    if (pub) {
-#pragma unroll
-      for (int c = 0; c < NC; ++c)
-        *reinterpret_cast<double2*>(slot + 2 * PL * c + 2 * j) = make_double2(x[2 * c], x[2 * c + 1]);
-      if (j == 0) ctl_store(&ctl[kReadyYe], (int)(kn + 1));
-    }
-    const double innov = my_val - xm;
+  // Scalar gain factors of this lane's row as a prospective observation (ensrf.py:85,91,135),
+  // with q = 1/sqrt(kdenom): rden = q^2, beta = 1/(1 + sqrt(err/kdenom)) = 1/(1 + sqrt(err) q).
+  // It is a ~25-deep dependent chain, so the chain wave starts it BEFORE the row update and the
+  // LDS publication of ye: by the time the other waves have read ye and finished their dot
+  // products the scalars are already in the ring.
+  struct Gain {
+    double innov, rden, beta, varye;
+  };
+  auto gain_of = [&](double mean_now, double varye) {
+    Gain g;
+    g.varye = varye;
+    g.innov = my_val - mean_now;
     const double kdenom = varye + my_err;
     const double q = fast_rsq(kdenom);
-    const double rden = q * q;
-    const double beta = fast_rcp(1.0 + my_sqrt_err * q);
+    g.rden = q * q;
+    g.beta = fast_rcp(1.0 + my_sqrt_err * q);
+    return g;
+  };
+  // publication of record kn into the LDS ring: ye first (raises ready_ye), then the scalars
+  auto write_record = [&](long kn, const Gain& g, bool pub) {
+    double* slot = ring + (size_t)(kn % kRing) * TS;
     double sv;
     switch (j) {
       case 0: sv = xm; break;
       case 1: sv = rmean; break;
-      case 2: sv = innov; break;
-      case 3: sv = rden; break;
-      case 4: sv = beta; break;
+      case 2: sv = g.innov; break;
+      case 3: sv = g.rden; break;
+      case 4: sv = g.beta; break;
       case 5: sv = my_asm ? 1.0 : 0.0; break;
-      case 6: sv = varye; break;
+      case 6: sv = g.varye; break;
       default: sv = 0.0; break;
     }
     if (pub) {
+#pragma unroll
+      for (int c = 0; c < NC; ++c)
+        *reinterpret_cast<double2*>(slot + 2 * PL * c + 2 * j) = make_double2(x[2 * c], x[2 * c + 1]);
       slot[PAD + j] = sv;
-      if (j == 0) ctl_store(&ctl[kReadySc], (int)(kn + 1));
-      o_prior_mean = xm;    // :66
-      o_prior_var = varye;  // :70
-      o_innov = innov;
-      o_rden = rden;
-      o_beta = beta;
+      if (j == 0) ctl_store(&ctl[kReadyYe], (int)(kn + 1));  // ye AND scalars of record kn are in the ring
+      o_prior_mean = xm;         // :66
+      o_prior_var = g.varye;     // :70
+      o_innov = g.innov;
+      o_rden = g.rden;
+      o_beta = g.beta;
     }
   };
   // wave-uniform wait until the ring slot of record kn may be recycled: every compute wave
@@ -323,7 +329,7 @@ __global__ __launch_bounds__(kPT) void k_pipe(const PipeArgs a) {
     }
   };
 
-  if (own0 == 0 && wave == 0 && P > 0) write_record(0, vfresh, i_loc == 0);
+  if (own0 == 0 && wave == 0 && P > 0) write_record(0, gain_of(xm, vfresh), i_loc == 0);
 
   // GC taper of ob k against this lane's row, prefetched two obs ahead
   double wq0 = 1.0, wq1 = 1.0;
@@ -364,58 +370,55 @@ __global__ __launch_bounds__(kPT) void k_pipe(const PipeArgs a) {
     EFA_STAMP(1);
     double y[2 * NC];
     lds_read_row<PL, NC>(slot, j, y);
+    const double2 s01 = *reinterpret_cast<const double2*>(slot + PAD);      // mye, mean(ye)
+    const double2 s23 = *reinterpret_cast<const double2*>(slot + PAD + 2);  // innov, rden
+    const double2 s45 = *reinterpret_cast<const double2*>(slot + PAD + 4);  // beta, active
+    const double var_k = slot[PAD + 6];
     const double w = wq0;
     wq0 = wq1;
     if (use_tw) wq1 = a.tw[(size_t)((k + 2 < P) ? k + 2 : P - 1) * R + row];
     const double dot = group_dot<PL, NC>(x, y);
     EFA_STAMP(2);
-    while (ctl_load(&ctl[kReadySc]) <= (int)k) {
-      if (ctl_load(&ctl[kBail]) != 0) {
-        bailed = true;
-        break;
-      }
-      if (--spins_left <= 0) {
-        give_up();
-        bailed = true;
-        break;
-      }
-      if (!chain_wave) __builtin_amdgcn_s_sleep(1);
-    }
-    if (bailed) break;
-    const double2 s01 = *reinterpret_cast<const double2*>(slot + PAD);      // mye, mean(ye)
-    const double2 s23 = *reinterpret_cast<const double2*>(slot + PAD + 2);  // innov, rden
-    const double2 s45 = *reinterpret_cast<const double2*>(slot + PAD + 4);  // beta, active
-    const double var_k = slot[PAD + 6];
     if (lane == 0) ctl_store(&ctl[kProg + wave], (int)k);  // record k consumed by this wave
     EFA_STAMP(3);
     const bool active = __builtin_amdgcn_readfirstlane((int)(s45.y != 0.0)) != 0;  // wave-uniform
-    double var_next = vfresh;          // variance of this row after ob k (meaningful for the publisher)
-    if (active) {
-      double kc = dot * rM1;                                // :95
-      if (a.loc_mode != 0) kc = (live ? w : 0.0) * kc;      // :115
-      const double km = kc * s23.y;                         // :119
-      xm = xm + km * s23.x;                                 // :130
-      const double kb = s45.x * km;                         // :136
-      // one-step variance recurrence from the fresh value (see header)
+    const bool own_k = (k >= own0) && (k < own1) && (i_loc == (int)(k - own0));
+    if (chain_wave) {
+      // ---- the serial chain of this step: ONE straight-line block so that the scheduler can
+      // interleave the long scalar chain (rsq/rcp + Newton) with the independent row update
+      double kc = dot * rM1;                              // :95
+      if (a.loc_mode != 0) kc = (live ? w : 0.0) * kc;    // :115
+      const double km = active ? kc * s23.y : 0.0;        // :119 (not assimilated: no update)
+      const double kb = s45.x * km;                       // :136
       const double cov = __builtin_fma(dot, invM, -(rmean * s01.y));
-      var_next = __builtin_fma(kb * kb, var_k, __builtin_fma(-2.0 * kb, cov, vfresh));
+      const double var_rec = __builtin_fma(kb * kb, var_k, __builtin_fma(-2.0 * kb, cov, vfresh));
+      const double var_next = active ? var_rec : vfresh;  // one-step recurrence (see header)
+      xm = xm + km * s23.x;                               // :130
+      Gain g = gain_of(xm, var_next);
       rmean = __builtin_fma(-kb, s01.y, rmean);
 #pragma unroll
       for (int c = 0; c < 2 * NC; ++c) x[c] = __builtin_fma(-kb, y[c], x[c]);  // :141
-      if (k >= own0 && k < own1 && i_loc == (int)(k - own0)) {
+      EFA_STAMP(4);
+      if (__any(pub && active && !(var_next > 0.01 * vfresh))) g = gain_of(xm, fresh_var());  // cancellation guard
+      // recycling guard, amortised: once per kGuardEvery records, for that many records ahead
+      if ((kn & (kGuardEvery - 1)) == 0 && kn + kGuardEvery > kRing) wait_slot_free(kn + kGuardEvery - 1);
+      if (bailed) break;
+      write_record(kn, g, pub);
+    } else if (active) {
+      double kc = dot * rM1;                              // :95
+      if (a.loc_mode != 0) kc = (live ? w : 0.0) * kc;    // :115
+      const double km = kc * s23.y;                       // :119
+      xm = xm + km * s23.x;                               // :130
+      const double kb = s45.x * km;                       // :136
+      rmean = __builtin_fma(-kb, s01.y, rmean);
+#pragma unroll
+      for (int c = 0; c < 2 * NC; ++c) x[c] = __builtin_fma(-kb, y[c], x[c]);  // :141
+      if (own_k) {
         const double f = 1.0 - kb;  // the ob's own row was scaled by (1 - kb)  (:144-149)
         o_post_var = (f * f) * o_prior_var;
         o_post_mean = xm;
         o_done = true;
       }
-    }
-    EFA_STAMP(4);
-    if (chain_wave) {
-      if (__any(pub && active && !(var_next > 0.01 * vfresh))) var_next = fresh_var();  // cancellation guard
-      // recycling guard, amortised: once per kGuardEvery records, for that many records ahead
-      if ((kn & (kGuardEvery - 1)) == 0 && kn + kGuardEvery > kRing) wait_slot_free(kn + kGuardEvery - 1);
-      if (bailed) break;
-      write_record(kn, var_next, pub);
     }
     EFA_STAMP(5);
     if (fresh_wave) vfresh = fresh_var();  // off the chain (uniform over the wave)
