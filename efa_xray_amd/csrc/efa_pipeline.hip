@@ -80,23 +80,19 @@ __device__ __forceinline__ void ctl_store(int* p, int v) {
   asm volatile("" ::: "memory");
   __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 }
-__device__ __forceinline__ double fast_rsq(double a) {  // 1/sqrt(a), two Newton steps on v_rsq_f64
-  double q = __builtin_amdgcn_rsq(a);
-#pragma unroll
-  for (int it = 0; it < 2; ++it) {
-    const double e = __builtin_fma(-a * q, q, 1.0);
-    q = __builtin_fma(0.5 * q, e, q);
-  }
-  return q;
+// v_rsq_f64 / v_rcp_f64 are accurate to 2e-8 relative on gfx950 (measured, tools/latency_probe.hip):
+// one Newton step squares that (rsq: 1.5 e^2, rcp: e^2) -- below double rounding; the second-order
+// term of the rsq step is added so that both land within ~1 ulp.
+__device__ __forceinline__ double fast_rsq(double a) {  // 1/sqrt(a)
+  const double q = __builtin_amdgcn_rsq(a);
+  const double e = __builtin_fma(-a * q, q, 1.0);           // 1 - a q^2
+  const double p = __builtin_fma(0.375, e, 0.5);            // 1/2 + 3/8 e
+  return __builtin_fma(q * e, p, q);                        // q (1 + e/2 + 3 e^2/8)
 }
-__device__ __forceinline__ double fast_rcp(double b) {  // 1/b, two Newton steps on v_rcp_f64
-  double r = __builtin_amdgcn_rcp(b);
-#pragma unroll
-  for (int it = 0; it < 2; ++it) {
-    const double e = __builtin_fma(-b, r, 1.0);
-    r = __builtin_fma(r, e, r);
-  }
-  return r;
+__device__ __forceinline__ double fast_rcp(double b) {  // 1/b
+  const double r = __builtin_amdgcn_rcp(b);
+  const double e = __builtin_fma(-b, r, 1.0);
+  return __builtin_fma(r, __builtin_fma(e, e, e), r);        // r (1 + e + e^2)
 }
 
 enum { kReadyYe = 0, kBail = 1, kReadySc = 2, kFwd = 3, kProg = 4 };  // ctl[] indices; prog[w] = ctl[kProg+w]
@@ -286,23 +282,18 @@ __global__ __launch_bounds__(kPT) void k_pipe(const PipeArgs a) {
   // publication of record kn into the LDS ring: ye first (raises ready_ye), then the scalars
   auto write_record = [&](long kn, const Gain& g, bool pub) {
     double* slot = ring + (size_t)(kn % kRing) * TS;
-    double sv;
-    switch (j) {
-      case 0: sv = xm; break;
-      case 1: sv = rmean; break;
-      case 2: sv = g.innov; break;
-      case 3: sv = g.rden; break;
-      case 4: sv = g.beta; break;
-      case 5: sv = my_asm ? 1.0 : 0.0; break;
-      case 6: sv = g.varye; break;
-      default: sv = 0.0; break;
-    }
     if (pub) {
 #pragma unroll
       for (int c = 0; c < NC; ++c)
         *reinterpret_cast<double2*>(slot + 2 * PL * c + 2 * j) = make_double2(x[2 * c], x[2 * c + 1]);
-      slot[PAD + j] = sv;
-      if (j == 0) ctl_store(&ctl[kReadyYe], (int)(kn + 1));  // ye AND scalars of record kn are in the ring
+      if (j == 0) {
+        double2* sc = reinterpret_cast<double2*>(slot + PAD);
+        sc[0] = make_double2(xm, rmean);
+        sc[1] = make_double2(g.innov, g.rden);
+        sc[2] = make_double2(g.beta, my_asm ? 1.0 : 0.0);
+        sc[3] = make_double2(g.varye, 0.0);
+        ctl_store(&ctl[kReadyYe], (int)(kn + 1));  // ye AND scalars of record kn are in the ring
+      }
       o_prior_mean = xm;         // :66
       o_prior_var = g.varye;     // :70
       o_innov = g.innov;
@@ -354,17 +345,24 @@ __global__ __launch_bounds__(kPT) void k_pipe(const PipeArgs a) {
     if (chain_wave) __builtin_amdgcn_s_setprio(3);
     else __builtin_amdgcn_s_setprio(0);
     EFA_STAMP(0);
-    while (ctl_load(&ctl[kReadyYe]) <= (int)k) {
-      if (ctl_load(&ctl[kBail]) != 0) {
-        bailed = true;
-        break;
+    {  // wait for record k: the chain wave polls back to back, the others doze between polls;
+       // the bail word and the spin budget are looked at once per 16 polls
+      int polls = 0;
+      while (ctl_load(&ctl[kReadyYe]) <= (int)k) {
+        if ((++polls & 15) == 0) {
+          if (ctl_load(&ctl[kBail]) != 0) {
+            bailed = true;
+            break;
+          }
+          spins_left -= 16;
+          if (spins_left <= 0) {
+            give_up();
+            bailed = true;
+            break;
+          }
+        }
+        if (!chain_wave) __builtin_amdgcn_s_sleep(1);
       }
-      if (--spins_left <= 0) {
-        give_up();
-        bailed = true;
-        break;
-      }
-      if (!chain_wave) __builtin_amdgcn_s_sleep(1);  // do not steal issue slots from the working waves
     }
     if (bailed) break;
     EFA_STAMP(1);
@@ -394,12 +392,22 @@ __global__ __launch_bounds__(kPT) void k_pipe(const PipeArgs a) {
       const double var_rec = __builtin_fma(kb * kb, var_k, __builtin_fma(-2.0 * kb, cov, vfresh));
       const double var_next = active ? var_rec : vfresh;  // one-step recurrence (see header)
       xm = xm + km * s23.x;                               // :130
-      Gain g = gain_of(xm, var_next);
-      rmean = __builtin_fma(-kb, s01.y, rmean);
+      Gain g;
+      if (!__any(pub && active && !(var_next > 0.01 * vfresh))) {
+        // fast path, one basic block: the gain chain is issued first and the independent
+        // row update fills its latency
+        g = gain_of(xm, var_next);
+        rmean = __builtin_fma(-kb, s01.y, rmean);
 #pragma unroll
-      for (int c = 0; c < 2 * NC; ++c) x[c] = __builtin_fma(-kb, y[c], x[c]);  // :141
+        for (int c = 0; c < 2 * NC; ++c) x[c] = __builtin_fma(-kb, y[c], x[c]);  // :141
+      } else {
+        // cancellation guard (rare): the recurrence lost digits, take the variance of the updated row
+        rmean = __builtin_fma(-kb, s01.y, rmean);
+#pragma unroll
+        for (int c = 0; c < 2 * NC; ++c) x[c] = __builtin_fma(-kb, y[c], x[c]);
+        g = gain_of(xm, fresh_var());
+      }
       EFA_STAMP(4);
-      if (__any(pub && active && !(var_next > 0.01 * vfresh))) g = gain_of(xm, fresh_var());  // cancellation guard
       // recycling guard, amortised: once per kGuardEvery records, for that many records ahead
       if ((kn & (kGuardEvery - 1)) == 0 && kn + kGuardEvery > kRing) wait_slot_free(kn + kGuardEvery - 1);
       if (bailed) break;
