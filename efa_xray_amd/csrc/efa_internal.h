@@ -76,7 +76,8 @@ struct DiagArgs {
 // no ordering between the elements (MI355X_MICROARCH.md, "R2 granule").
 constexpr unsigned long long kTrajSentinel = 0x7FF8DEADBEEF0001ull;  // a NaN payload no arithmetic produces
 constexpr int kTrajScalars = 8;  // mye, mean(ye), innov, rden, beta, active, prior_var, (unused)
-inline int traj_pad(int M) { return 16 * ((M + 15) / 16); }             // 8 lanes x 2 doubles per chunk
+constexpr int kPipeLanes = 4;    // lanes per row in the pipeline kernel (== its compute waves per workgroup)
+inline int traj_pad(int M) { return 2 * kPipeLanes * ((M + 2 * kPipeLanes - 1) / (2 * kPipeLanes)); }
 inline long traj_stride(int M) { return traj_pad(M) + kTrajScalars; }
 constexpr int kPipeRowsPerWG = 64;
 constexpr int kPipeMaxWGs = 256;  // one 576-thread workgroup per CU: all co-resident

@@ -45,9 +45,9 @@
 namespace efa {
 namespace {
 
-constexpr int kCW = 8;                 // compute waves per workgroup
+constexpr int kCW = kPipeLanes;        // compute waves per workgroup (one per SIMD when 4)
 constexpr int kPT = 64 * (kCW + 1);    // + one loader wave
-constexpr int PL = 8;                  // lanes per row
+constexpr int PL = kPipeLanes;         // lanes per row
 constexpr int kRing = 32;              // LDS ring slots
 constexpr int kGuardEvery = 8;         // the slot-recycling guard is evaluated once per this many records
 constexpr int kPoll = 4;               // records fetched per loader round trip
@@ -70,10 +70,10 @@ __device__ __forceinline__ int ctl_load_lane(const int* p) {  // per-lane addres
 // spin / bail logic compiles to scalar branches instead of exec-mask bookkeeping
 __device__ __forceinline__ int ctl_load(const int* p) { return __builtin_amdgcn_readfirstlane(ctl_load_lane(p)); }
 // minimum over the 8 lanes of a row group (DPP, no LDS round trip), same value in all 8 lanes
-__device__ __forceinline__ int group8_min(int v) {
+__device__ __forceinline__ int group8_min(int v) {  // over the PL lanes of a row group
   v = min(v, __builtin_amdgcn_mov_dpp(v, 0xB1, 0xF, 0xF, true));
   v = min(v, __builtin_amdgcn_mov_dpp(v, 0x4E, 0xF, 0xF, true));
-  v = min(v, __builtin_amdgcn_mov_dpp(v, 0x141, 0xF, 0xF, true));
+  if (PL >= 8) v = min(v, __builtin_amdgcn_mov_dpp(v, 0x141, 0xF, 0xF, true));
   return v;
 }
 __device__ __forceinline__ void ctl_store(int* p, int v) {
@@ -99,7 +99,7 @@ enum { kReadyYe = 0, kBail = 1, kReadySc = 2, kFwd = 3, kProg = 4 };  // ctl[] i
 
 template <int NC>
 __global__ __launch_bounds__(kPT) void k_pipe(const PipeArgs a) {
-  constexpr int PAD = 16 * NC;  // ye slots of a record
+  constexpr int PAD = 2 * PL * NC;  // ye slots of a record
   constexpr int TS = PAD + kTrajScalars;
   constexpr int EPL = (TS + 63) / 64;  // record elements per lane of the loader wave
   __shared__ __align__(16) double ring[kRing * TS];
@@ -180,7 +180,7 @@ __global__ __launch_bounds__(kPT) void k_pipe(const PipeArgs a) {
       const long need = next + cnt - 1 - kRing;  // all prog[w] must be >= need
       if (need >= 0) {
         for (;;) {
-          const int mn = __builtin_amdgcn_readfirstlane(group8_min(ctl_load_lane(&ctl[kProg + (lane & 7)])));
+          const int mn = __builtin_amdgcn_readfirstlane(group8_min(ctl_load_lane(&ctl[kProg + (lane & (kCW - 1))])));
           if (mn >= (int)need) break;
           if (--spins_left <= 0) {
             failed = true;
@@ -215,7 +215,7 @@ __global__ __launch_bounds__(kPT) void k_pipe(const PipeArgs a) {
   // compute waves
   // =====================================================================================
   const int j = lane & (PL - 1);
-  const int grp = lane >> 3;
+  const int grp = lane / PL;
   const int i_loc = wave + kCW * grp;  // local row / ob index 0..63: consecutive obs in different waves
   const long row = own0 + i_loc;
   const bool live = row < R;
@@ -487,12 +487,12 @@ hipError_t pipe_launch(const PipeArgs& a, hipStream_t s) {
 }  // namespace
 
 bool pipeline_supported(int M, long R) {
-  return M >= 2 && M <= 128 && R > 0 && (R + kPipeRowsPerWG - 1) / kPipeRowsPerWG <= kPipeMaxWGs;
+  return M >= 2 && M <= 16 * 2 * kPipeLanes && M <= 128 && R > 0 && (R + kPipeRowsPerWG - 1) / kPipeRowsPerWG <= kPipeMaxWGs;
 }
 
 hipError_t launch_pipeline(const PipeArgs& a, hipStream_t s) {
   if (!pipeline_supported(a.M, a.R) || a.P <= 0) return hipErrorInvalidValue;
-  switch ((a.M + 15) / 16) {
+  switch ((a.M + 2 * PL - 1) / (2 * PL)) {
     case 1: return pipe_launch<1>(a, s);
     case 2: return pipe_launch<2>(a, s);
     case 3: return pipe_launch<3>(a, s);
@@ -501,6 +501,14 @@ hipError_t launch_pipeline(const PipeArgs& a, hipStream_t s) {
     case 6: return pipe_launch<6>(a, s);
     case 7: return pipe_launch<7>(a, s);
     case 8: return pipe_launch<8>(a, s);
+    case 9: return pipe_launch<9>(a, s);
+    case 10: return pipe_launch<10>(a, s);
+    case 11: return pipe_launch<11>(a, s);
+    case 12: return pipe_launch<12>(a, s);
+    case 13: return pipe_launch<13>(a, s);
+    case 14: return pipe_launch<14>(a, s);
+    case 15: return pipe_launch<15>(a, s);
+    case 16: return pipe_launch<16>(a, s);
     default: return hipErrorInvalidValue;
   }
 }
