@@ -82,6 +82,7 @@ struct efa_ctx {
   long use_pipeline = 1;   // persistent Phase-A kernel when it applies (else per-batch kernels)
   long spin_limit = 4000000;
   long pipe_debug = 0;
+  long gc_onepass = 1;     // localised state sweep in one pass with per-column-block active lists
 
   // --- trajectory recorded by the last obs phase --------------------------
   bool have_traj = false;
@@ -101,6 +102,9 @@ struct efa_ctx {
   DevBuf Yw, ymw;  // obs block workspace [(P+M)][M], [(P+M)]
   // --- state phase workspaces ---------------------------------------------
   DevBuf W;           // taper table [nb][ncol]
+  DevBuf gc_cnt, gc_off, gc_idx, gc_wts;  // one-pass GC sweep: CSR active lists
+  std::vector<int> h_cnt;
+  std::vector<long> h_off;
   DevBuf glat, glon;  // grid lat/lon [ncol]
   DevBuf xm_ws;       // means for efa_state_cycle_dev
   // --- host-memory API buffers ----------------------------------------------
@@ -374,12 +378,65 @@ int prepare_grid(efa_ctx* c, const double* grid_lat, const double* grid_lon, lon
   return EFA_OK;
 }
 
+// ---- Phase B, localised, one pass (efa_gcsweep.hip) --------------------------------------
+int state_gc_onepass(efa_ctx* c, long rows, const double* xm_in, const double* Xp_in, double* xm_out, double* Xp_out,
+                     long ncol, long n_lead, int fused_members) {
+  const int M = c->M;
+  const long P = c->P;
+  hipStream_t s = c->stream;
+  const long nblk = gc_num_blocks(ncol);
+  EFA_TRY(c->gc_cnt.reserve((size_t)nblk * sizeof(int)));
+  EFA_TRY(c->gc_off.reserve((size_t)(nblk + 1) * sizeof(long)));
+  EFA_HIP(launch_gc_count(ncol, P, c->glat.as<double>(), c->glon.as<double>(), c->ob_lat.as<double>(),
+                          c->ob_lon.as<double>(), c->ob_hw.as<double>(), c->coef.as<double>(), c->gc_cnt.as<int>(), s));
+  c->h_cnt.resize((size_t)nblk);
+  c->h_off.resize((size_t)nblk + 1);
+  EFA_HIP(hipMemcpyAsync(c->h_cnt.data(), c->gc_cnt.p, (size_t)nblk * sizeof(int), hipMemcpyDeviceToHost, s));
+  EFA_HIP(hipStreamSynchronize(s));
+  long nnz = 0;
+  for (long b = 0; b < nblk; ++b) {
+    c->h_off[b] = nnz;
+    nnz += c->h_cnt[b];
+  }
+  c->h_off[nblk] = nnz;
+  EFA_HIP(hipMemcpyAsync(c->gc_off.p, c->h_off.data(), (size_t)(nblk + 1) * sizeof(long), hipMemcpyHostToDevice, s));
+  EFA_TRY(c->gc_idx.reserve((size_t)(nnz ? nnz : 1) * sizeof(int)));
+  EFA_TRY(c->gc_wts.reserve((size_t)(nnz ? nnz : 1) * 16 * sizeof(double)));
+  if (nnz)
+    EFA_HIP(launch_gc_fill(ncol, P, c->glat.as<double>(), c->glon.as<double>(), c->ob_lat.as<double>(),
+                           c->ob_lon.as<double>(), c->ob_hw.as<double>(), c->coef.as<double>(), c->gc_off.as<long>(),
+                           c->gc_idx.as<int>(), c->gc_wts.as<double>(), s));
+  GcSweepArgs g{};
+  g.ncol = ncol;
+  g.n_lead = n_lead;
+  g.M = M;
+  g.nblk = nblk;
+  g.off = c->gc_off.as<long>();
+  g.idx = c->gc_idx.as<int>();
+  g.wts = c->gc_wts.as<double>();
+  g.coef = c->coef.as<double>();
+  g.Ye = c->ye_ptr;
+  g.ye_stride = c->ye_stride;
+  g.Xin = Xp_in;
+  g.xin = xm_in;
+  g.Xout = Xp_out;
+  g.xout = xm_out;
+  g.fused_members = fused_members;
+  EFA_HIP(launch_sweep_gc(g, s));
+  EFA_HIP(hipStreamSynchronize(s));  // h_off is reused by the next call
+  c->state_launches++;
+  (void)rows;
+  return EFA_OK;
+}
+
 // ---- Phase B (perturbation form) ------------------------------------------
 int state_sweeps(efa_ctx* c, long rows, const double* xm_in, const double* Xp_in, double* xm_out, double* Xp_out,
                  long ncol) {
   const int M = c->M;
   const long P = c->P;
   hipStream_t s = c->stream;
+  if (c->loc_mode == EFA_LOC_GC && c->gc_onepass && M <= 128 && c->n_active > 0)
+    return state_gc_onepass(c, rows, xm_in, Xp_in, xm_out, Xp_out, ncol, rows / ncol, 0);
   const long B = effective_batch(c, M);
   bool first = true;
   for (long b0 = 0; b0 < P; b0 += B) {
@@ -526,7 +583,7 @@ int efa_ctx_destroy(efa_ctx* c) {
   if (c->stream) (void)hipStreamSynchronize(c->stream);
   DevBuf* bufs[] = {&c->Ye_rec, &c->coef, &c->ob_val, &c->ob_err, &c->ob_asm, &c->ob_lat, &c->ob_lon, &c->ob_hw,
                     &c->d_prior_mean, &c->d_prior_var, &c->d_post_mean, &c->d_post_var, &c->d_assimilated,
-                    &c->Yw, &c->ymw, &c->traj, &c->tw_mat, &c->status, &c->dbg, &c->W, &c->glat, &c->glon, &c->xm_ws, &c->h_xm, &c->h_Xp, &c->h_ym, &c->h_Yp};
+                    &c->Yw, &c->ymw, &c->traj, &c->tw_mat, &c->status, &c->dbg, &c->W, &c->gc_cnt, &c->gc_off, &c->gc_idx, &c->gc_wts, &c->glat, &c->glon, &c->xm_ws, &c->h_xm, &c->h_Xp, &c->h_ym, &c->h_Yp};
   for (DevBuf* b : bufs) b->release();
   for (int i = 0; i < 4; ++i)
     if (c->ev[i]) (void)hipEventDestroy(c->ev[i]);
@@ -555,6 +612,8 @@ int efa_ctx_set_option(efa_ctx* c, const char* key, long value) {
     c->timing = value ? 1 : 0;
   } else if (!strcmp(key, "pipeline")) {
     c->use_pipeline = value ? 1 : 0;
+  } else if (!strcmp(key, "gc_onepass")) {
+    c->gc_onepass = value ? 1 : 0;
   } else if (!strcmp(key, "own_stream")) {
     c->stream = c->own_stream;  // back to the context's private non-blocking stream
   } else if (!strcmp(key, "pipe_debug")) {
@@ -709,6 +768,9 @@ int efa_state_cycle_dev(efa_ctx* c, long rows, int M, const double* X_dev, doubl
     EFA_HIP(efa::launch_transform(t, s));
     c->state_launches = 1;
     c->path_taken = EFA_PATH_TRANSFORM;
+  } else if (c->loc_mode == EFA_LOC_GC && c->gc_onepass && M <= 128 && c->n_active > 0) {
+    // localised: prior members -> posterior members in one read + one write of the state
+    EFA_TRY(state_gc_onepass(c, rows, nullptr, X_dev, nullptr, post_dev, ncol, n_lead, 1));
   } else {
     EFA_TRY(c->xm_ws.reserve((size_t)rows * sizeof(double)));
     double* xm = c->xm_ws.as<double>();

@@ -1,0 +1,239 @@
+// Localised (Gaspari-Cohn) state sweep in ONE pass over the state: every row is loaded once,
+// all observations whose taper is non-zero for it are applied in order, and it is stored once.
+//
+// Reference semantics (ensrf.py:99-115): kcov is multiplied by a taper that depends only on the
+// (y, x) column (distance_to_point + gaspari_cohn, broadcast over variable x time), and is
+// exactly 0 beyond 2 x halfwidth, where the update leaves the row bit-unchanged.  So
+//   1. k_gc_build evaluates haversine + Gaspari-Cohn ONCE per (column, observation) -- not per
+//      state row -- and keeps, per block of 16 columns, the ascending list of observations with
+//      any non-zero weight together with the 16 weights (CSR: off / idx / wts);
+//   2. k_sweep_gc gives each workgroup one column block; its 4 waves walk the n_lead
+//      variable x time slabs of those 16 columns (quad per row: 16 rows = 10 KB contiguous),
+//      and for each slab loop over the block's active list only.  ye rows and coefficients of
+//      the active observations come from L2 (the recorded trajectory is a few MB), software
+//      prefetched one entry ahead; the taper block is re-read by the 148 slabs from L1/L2.
+// Work drops from P passes' worth to (active fraction) x P; HBM traffic to one read + one write.
+#include "efa_device.h"
+#include "efa_internal.h"
+#include "efa_rows.h"
+
+namespace efa {
+namespace {
+
+constexpr int kBlkCols = 16;  // columns per block == rows per wave in the quad layout
+
+// One workgroup per column block; thread t: column c = t & 15, observation slot o = t >> 4
+// (16 observations per chunk, visited in ascending order).  FILL = false: count only.
+template <bool FILL>
+__global__ __launch_bounds__(256) void k_gc_build(long ncol, long P, const double* __restrict__ glat,
+                                                  const double* __restrict__ glon,
+                                                  const double* __restrict__ ob_lat,
+                                                  const double* __restrict__ ob_lon,
+                                                  const double* __restrict__ ob_hw,
+                                                  const double* __restrict__ coef, int* __restrict__ cnt,
+                                                  const long* __restrict__ off, int* __restrict__ idx,
+                                                  double* __restrict__ wts) {
+  __shared__ int flags[16];
+  __shared__ long running;
+  const long b = blockIdx.x;
+  const int t = threadIdx.x;
+  const int c = t & 15, o = t >> 4;
+  const long col = b * kBlkCols + c;
+  const bool col_ok = col < ncol;
+  const double la = col_ok ? glat[col] : 0.0, lo = col_ok ? glon[col] : 0.0;
+  if (t == 0) running = FILL ? off[b] : 0;
+  __syncthreads();
+  for (long k0 = 0; k0 < P; k0 += 16) {
+    const long k = k0 + o;
+    double w = 0.0;
+    if (k < P && col_ok && coef[k * kCoefStride + 3] != 0.0)
+      w = gaspari_cohn(distance_to_point_km(la, lo, ob_lat[k], ob_lon[k]), ob_hw[k]);
+    const unsigned long long bal = __ballot(w != 0.0);
+    const int g = (t & 63) >> 4;
+    const bool any = ((bal >> (16 * g)) & 0xFFFFull) != 0ull;
+    if (c == 0) flags[o] = any ? 1 : 0;
+    __syncthreads();
+    int before = 0, total = 0;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      const int f = flags[i];
+      before += (i < o) ? f : 0;
+      total += f;
+    }
+    const long base = running;
+    if (FILL && any) {
+      const long e = base + before;
+      if (c == 0) idx[e] = (int)k;
+      wts[e * kBlkCols + c] = w;
+    }
+    __syncthreads();
+    if (t == 0) running = base + total;
+    __syncthreads();
+  }
+  if (!FILL && t == 0) cnt[b] = (int)running;
+}
+
+struct Entry {  // one active observation as seen by a lane
+  double w;     // taper of the lane's row
+  double c0, c1, c2;  // innov, rden, beta
+};
+
+template <int NC, bool VEC, bool FUSED>
+__global__ __launch_bounds__(256) void k_sweep_gc(const GcSweepArgs a) {
+  constexpr int L = 4;
+  const int tid = threadIdx.x;
+  const int wave = tid >> 6, lane = tid & 63;
+  const int j = lane & 3, r = lane >> 2;
+  const long b = blockIdx.x;
+  const long col = b * kBlkCols + r;
+  const bool live = col < a.ncol;
+  const int M = a.M;
+  const double rM1 = 1.0 / (double)(M - 1);
+  const long e0 = a.off[b], e1 = a.off[b + 1];
+
+  auto load_ye = [&](long k, double (&y)[2 * NC]) {
+    const double* p = a.Ye + (size_t)k * a.ye_stride;
+#pragma unroll
+    for (int c = 0; c < NC; ++c) {
+      const int m0 = 2 * L * c + 2 * j;
+      if (VEC) {
+        if (m0 < M) {
+          const double2 v = *reinterpret_cast<const double2*>(p + m0);
+          y[2 * c] = v.x;
+          y[2 * c + 1] = v.y;
+        } else {
+          y[2 * c] = 0.0;
+          y[2 * c + 1] = 0.0;
+        }
+      } else {
+        y[2 * c] = (m0 < M) ? p[m0] : 0.0;
+        y[2 * c + 1] = (m0 + 1 < M) ? p[m0 + 1] : 0.0;
+      }
+    }
+  };
+  auto load_entry = [&](long e, Entry& en, double (&y)[2 * NC]) {
+    const int k = a.idx[e];
+    en.w = live ? a.wts[e * kBlkCols + r] : 0.0;
+    const double* ck = a.coef + (size_t)k * kCoefStride;
+    en.c0 = ck[0];
+    en.c1 = ck[1];
+    en.c2 = ck[2];
+    load_ye(k, y);
+  };
+
+  for (long lead = wave; lead < a.n_lead; lead += 4) {
+    const long row = lead * a.ncol + col;
+    double x[2 * NC];
+    double xm = 0.0;
+    if (live) {
+      load_row<L, NC, VEC>(a.Xin + (size_t)row * M, M, j, x);
+      if (!FUSED) xm = a.xin[row];
+    } else {
+#pragma unroll
+      for (int c = 0; c < 2 * NC; ++c) x[c] = 0.0;
+    }
+    if (FUSED) {  // prior members in: remove the ensemble mean (assimilation.py:146-147)
+      xm = group_rowsum<L, NC>(x) / (double)M;
+#pragma unroll
+      for (int c = 0; c < 2 * NC; ++c) x[c] -= xm;  // padding slots never reach the output or the dot
+    }
+    if (e1 > e0) {
+      Entry cur, nxt;
+      double y[2 * NC], yn[2 * NC];
+      load_entry(e0, cur, y);
+      for (long e = e0; e < e1; ++e) {
+        const long en = (e + 1 < e1) ? e + 1 : e;  // prefetch (the last one harmlessly reloads itself)
+        load_entry(en, nxt, yn);
+        const double dot = group_dot<L, NC>(x, y);
+        double kc = dot * rM1;           // :95
+        kc = cur.w * kc;                 // :115
+        const double km = kc * cur.c1;   // :119
+        xm = xm + km * cur.c0;           // :130
+        const double kb = cur.c2 * km;   // :136
+#pragma unroll
+        for (int c = 0; c < 2 * NC; ++c) x[c] = __builtin_fma(-kb, y[c], x[c]);  // :141
+        cur = nxt;
+#pragma unroll
+        for (int c = 0; c < 2 * NC; ++c) y[c] = yn[c];
+      }
+    }
+    if (live) {
+      if (FUSED) {  // posterior members out (assimilation.py:168)
+#pragma unroll
+        for (int c = 0; c < 2 * NC; ++c) x[c] += xm;
+      }
+      store_row<L, NC, VEC>(a.Xout + (size_t)row * M, M, j, x);
+      if (!FUSED && j == 0) a.xout[row] = xm;
+    }
+  }
+}
+
+inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
+
+template <int NC>
+hipError_t gc_launch(const GcSweepArgs& a, hipStream_t s) {
+  const bool vec = (a.M % 2 == 0) && (a.ye_stride % 2 == 0) && aligned16(a.Xin) && aligned16(a.Xout) && aligned16(a.Ye);
+  const dim3 grid((unsigned)a.nblk), block(256);
+  if (a.fused_members) {
+    if (vec) hipLaunchKernelGGL((k_sweep_gc<NC, true, true>), grid, block, 0, s, a);
+    else hipLaunchKernelGGL((k_sweep_gc<NC, false, true>), grid, block, 0, s, a);
+  } else {
+    if (vec) hipLaunchKernelGGL((k_sweep_gc<NC, true, false>), grid, block, 0, s, a);
+    else hipLaunchKernelGGL((k_sweep_gc<NC, false, false>), grid, block, 0, s, a);
+  }
+  return hipGetLastError();
+}
+
+}  // namespace
+
+long gc_num_blocks(long ncol) { return (ncol + kBlkCols - 1) / kBlkCols; }
+
+hipError_t launch_gc_count(long ncol, long P, const double* glat, const double* glon, const double* ob_lat,
+                           const double* ob_lon, const double* ob_hw, const double* coef, int* cnt, hipStream_t s) {
+  const long nblk = gc_num_blocks(ncol);
+  if (nblk <= 0) return hipSuccess;
+  hipLaunchKernelGGL((k_gc_build<false>), dim3((unsigned)nblk), dim3(256), 0, s, ncol, P, glat, glon, ob_lat, ob_lon,
+                     ob_hw, coef, cnt, nullptr, nullptr, nullptr);
+  return hipGetLastError();
+}
+
+hipError_t launch_gc_fill(long ncol, long P, const double* glat, const double* glon, const double* ob_lat,
+                          const double* ob_lon, const double* ob_hw, const double* coef, const long* off, int* idx,
+                          double* wts, hipStream_t s) {
+  const long nblk = gc_num_blocks(ncol);
+  if (nblk <= 0) return hipSuccess;
+  hipLaunchKernelGGL((k_gc_build<true>), dim3((unsigned)nblk), dim3(256), 0, s, ncol, P, glat, glon, ob_lat, ob_lon,
+                     ob_hw, coef, nullptr, off, idx, wts);
+  return hipGetLastError();
+}
+
+hipError_t launch_sweep_gc(const GcSweepArgs& a, hipStream_t s) {
+  if (a.M < 2 || a.M > kMaxMembers) return hipErrorInvalidValue;
+  if (a.nblk <= 0 || a.n_lead <= 0) return hipSuccess;
+  int nch = (a.M + 7) / 8;
+  if (nch > 16) nch = (nch <= 20) ? 20 : (nch <= 24) ? 24 : 32;
+  switch (nch) {
+    case 1: return gc_launch<1>(a, s);
+    case 2: return gc_launch<2>(a, s);
+    case 3: return gc_launch<3>(a, s);
+    case 4: return gc_launch<4>(a, s);
+    case 5: return gc_launch<5>(a, s);
+    case 6: return gc_launch<6>(a, s);
+    case 7: return gc_launch<7>(a, s);
+    case 8: return gc_launch<8>(a, s);
+    case 9: return gc_launch<9>(a, s);
+    case 10: return gc_launch<10>(a, s);
+    case 11: return gc_launch<11>(a, s);
+    case 12: return gc_launch<12>(a, s);
+    case 13: return gc_launch<13>(a, s);
+    case 14: return gc_launch<14>(a, s);
+    case 15: return gc_launch<15>(a, s);
+    case 16: return gc_launch<16>(a, s);
+    case 20: return gc_launch<20>(a, s);
+    case 24: return gc_launch<24>(a, s);
+    case 32: return gc_launch<32>(a, s);
+    default: return hipErrorInvalidValue;
+  }
+}
+
+}  // namespace efa

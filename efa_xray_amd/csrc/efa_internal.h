@@ -112,6 +112,31 @@ hipError_t launch_fill_u64(unsigned long long* p, size_t n, unsigned long long v
 hipError_t launch_obs_taper_matrix(long P, long R, const double* ob_lat, const double* ob_lon,
                                    const double* ob_hw, double* tw, hipStream_t s);
 
+// ---- one-pass localised sweep (efa_gcsweep.hip) ---------------------------------------
+struct GcSweepArgs {
+  long ncol, n_lead;
+  int M;
+  long nblk;            // column blocks of 16
+  const long* off;      // [nblk+1] CSR offsets into idx / wts
+  const int* idx;       // [nnz] observation index, ascending within a block
+  const double* wts;    // [nnz][16] taper of the block's 16 columns
+  const double* coef;   // [P][kCoefStride]
+  const double* Ye;     // recorded ye rows
+  long ye_stride;
+  const double* Xin;    // [n_lead*ncol][M] perturbations (or prior members when fused_members)
+  const double* xin;    // [n_lead*ncol] means (unused when fused_members)
+  double* Xout;
+  double* xout;
+  int fused_members;
+};
+long gc_num_blocks(long ncol);
+hipError_t launch_gc_count(long ncol, long P, const double* glat, const double* glon, const double* ob_lat,
+                           const double* ob_lon, const double* ob_hw, const double* coef, int* cnt, hipStream_t s);
+hipError_t launch_gc_fill(long ncol, long P, const double* glat, const double* glon, const double* ob_lat,
+                          const double* ob_lon, const double* ob_hw, const double* coef, const long* off, int* idx,
+                          double* wts, hipStream_t s);
+hipError_t launch_sweep_gc(const GcSweepArgs& a, hipStream_t s);
+
 struct TransformArgs {
   const double* Xin;  // [rows][M] perturbations, or full members when fused_members
   const double* xin;  // [rows] means (unused when fused_members)

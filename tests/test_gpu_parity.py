@@ -465,3 +465,47 @@ def test_dense_contraction_f32_vs_float64(N, M, P):
     for m in range(M):
         chain = (chain.astype(np.float64) + X[0, m].astype(np.float64) * Ye[:, m].astype(np.float64)).astype(np.float32)
     assert np.allclose(C[0], chain, rtol=2e-6, atol=1e-6)
+
+
+@pytest.mark.parametrize("onepass", [1, 0])
+def test_localised_sweep_many_obs_vs_oracle(onepass):
+    """GC with several hundred obs on a 48 x 64 grid x 3 slabs: the one-pass active-list sweep and the
+    per-batch taper-table sweep against the oracle; state_cycle (members in -> members out) too."""
+    c = _random_case(71, 3 * 48 * 64, 40, 420, True, ncol=48 * 64)
+    c["hw"][:] = np.random.default_rng(5).uniform(300, 2500, c["P"])
+    xam, Xap, diag = _run_oracle(c)
+    ctx = _ctx()
+    ctx.set_option("gc_onepass", onepass)
+    try:
+        h_xam, h_Xap, h_diag = _run_hip(c, path="sweep")
+        assert_parity(h_xam, xam, "xam")
+        assert_parity(h_Xap, Xap, "Xap")
+        for key in ("prior_mean", "prior_var", "post_mean", "post_var"):
+            assert_parity(h_diag[key], diag[key], key)
+        # fused members path
+        N, M, P = c["N"], c["M"], c["P"]
+        X = ctx.to_device(c["X"])
+        Yp = ctx.to_device(c["HX"])
+        ym = ctx.empty((P,))
+        ctx.form_perts(P, M, Yp, ym, Yp)
+        ctx.obs_phase(M, P, ym, Yp, c["val"], c["err"], c["asm"], 1, c["ob_lat"], c["ob_lon"], c["hw"])
+        post = ctx.empty((N, M))
+        ctx.state_cycle(N, M, X, post, c["lat"].reshape(-1), c["lon"].reshape(-1), c["n_lead"])
+        assert_parity(post.download(), orc.format_posterior_state(xam, Xap, N), "post (state_cycle)")
+    finally:
+        ctx.set_option("gc_onepass", 1)
+
+
+@pytest.mark.parametrize("name", ["G2", "G3", "G5", "G6", "G8"])
+def test_gc_goldens_per_batch_table_path(name):
+    """The per-batch taper-table sweep (gc_onepass=0) stays reference-exact on the GC goldens."""
+    g = load_golden(name)
+    N, xbm, Xbp = prior_arrays(g)
+    ctx = _ctx()
+    ctx.set_option("gc_onepass", 0)
+    try:
+        ctx.ensrf_update_host(xbm, Xbp, N, g["ob_value"], g["ob_error"], g["ob_assim"], **golden_kwargs(g))
+    finally:
+        ctx.set_option("gc_onepass", 1)
+    assert_parity(xbm, g["xam"], name + " xam")
+    assert_parity(orc.format_posterior_state(xbm, Xbp, N), g["post"], name + " post")
