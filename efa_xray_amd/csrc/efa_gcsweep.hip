@@ -46,8 +46,13 @@ __global__ __launch_bounds__(256) void k_gc_build(long ncol, long P, const doubl
   for (long k0 = 0; k0 < P; k0 += 16) {
     const long k = k0 + o;
     double w = 0.0;
-    if (k < P && col_ok && coef[k * kCoefStride + 3] != 0.0)
-      w = gaspari_cohn(distance_to_point_km(la, lo, ob_lat[k], ob_lon[k]), ob_hw[k]);
+    if (k < P && col_ok && coef[k * kCoefStride + 3] != 0.0) {
+      // cheap exact rejection: the great-circle distance is at least R*|dlat|; beyond 2 x halfwidth
+      // the Gaspari-Cohn weight is exactly 0, so the trigonometry can be skipped
+      const double hw = ob_hw[k], olat = ob_lat[k];
+      if (kEarthRadiusKm * fabs(radians(olat - la)) <= 2.0 * fabs(hw) * (1.0 + 1e-9) || !(hw == hw))
+        w = gaspari_cohn(distance_to_point_km(la, lo, olat, ob_lon[k]), hw);
+    }
     const unsigned long long bal = __ballot(w != 0.0);
     const int g = (t & 63) >> 4;
     const bool any = ((bal >> (16 * g)) & 0xFFFFull) != 0ull;
@@ -73,55 +78,33 @@ __global__ __launch_bounds__(256) void k_gc_build(long ncol, long P, const doubl
   if (!FILL && t == 0) cnt[b] = (int)running;
 }
 
-struct Entry {  // one active observation as seen by a lane
-  double w;     // taper of the lane's row
-  double c0, c1, c2;  // innov, rden, beta
-};
+constexpr int kChunk = 32;  // active observations staged in LDS at a time
 
+// Workgroup = one column block, 4 waves = 4 variable x time slabs processed in lock step: the
+// block's active observations are staged chunk by chunk into LDS ONCE per group of 4 slabs (ye
+// rows, tapers, coefficients), so the per-lane traffic of the inner loop is LDS only.  Fetching ye
+// per lane straight from L2 made the kernel vector-memory-issue bound (10 x 1 KB requests per
+// wave and observation through one 64 B/clk path per CU).
 template <int NC, bool VEC, bool FUSED>
 __global__ __launch_bounds__(256) void k_sweep_gc(const GcSweepArgs a) {
   constexpr int L = 4;
+  constexpr int S = 2 * L * NC;  // padded ye row (doubles)
+  __shared__ __align__(16) double ye_s[kChunk * S];
+  __shared__ __align__(16) double wt_s[kChunk * kBlkCols];
+  __shared__ __align__(16) double cf_s[kChunk * 4];
   const int tid = threadIdx.x;
   const int wave = tid >> 6, lane = tid & 63;
   const int j = lane & 3, r = lane >> 2;
   const long b = blockIdx.x;
   const long col = b * kBlkCols + r;
-  const bool live = col < a.ncol;
+  const bool col_ok = col < a.ncol;
   const int M = a.M;
   const double rM1 = 1.0 / (double)(M - 1);
   const long e0 = a.off[b], e1 = a.off[b + 1];
 
-  auto load_ye = [&](long k, double (&y)[2 * NC]) {
-    const double* p = a.Ye + (size_t)k * a.ye_stride;
-#pragma unroll
-    for (int c = 0; c < NC; ++c) {
-      const int m0 = 2 * L * c + 2 * j;
-      if (VEC) {
-        if (m0 < M) {
-          const double2 v = *reinterpret_cast<const double2*>(p + m0);
-          y[2 * c] = v.x;
-          y[2 * c + 1] = v.y;
-        } else {
-          y[2 * c] = 0.0;
-          y[2 * c + 1] = 0.0;
-        }
-      } else {
-        y[2 * c] = (m0 < M) ? p[m0] : 0.0;
-        y[2 * c + 1] = (m0 + 1 < M) ? p[m0 + 1] : 0.0;
-      }
-    }
-  };
-  auto load_entry = [&](long e, Entry& en, double (&y)[2 * NC]) {
-    const int k = a.idx[e];
-    en.w = live ? a.wts[e * kBlkCols + r] : 0.0;
-    const double* ck = a.coef + (size_t)k * kCoefStride;
-    en.c0 = ck[0];
-    en.c1 = ck[1];
-    en.c2 = ck[2];
-    load_ye(k, y);
-  };
-
-  for (long lead = wave; lead < a.n_lead; lead += 4) {
+  for (long lead0 = 0; lead0 < a.n_lead; lead0 += 4) {
+    const long lead = lead0 + wave;
+    const bool live = col_ok && lead < a.n_lead;
     const long row = lead * a.ncol + col;
     double x[2 * NC];
     double xm = 0.0;
@@ -137,24 +120,47 @@ __global__ __launch_bounds__(256) void k_sweep_gc(const GcSweepArgs a) {
 #pragma unroll
       for (int c = 0; c < 2 * NC; ++c) x[c] -= xm;  // padding slots never reach the output or the dot
     }
-    if (e1 > e0) {
-      Entry cur, nxt;
-      double y[2 * NC], yn[2 * NC];
-      load_entry(e0, cur, y);
-      for (long e = e0; e < e1; ++e) {
-        const long en = (e + 1 < e1) ? e + 1 : e;  // prefetch (the last one harmlessly reloads itself)
-        load_entry(en, nxt, yn);
+    for (long c0 = e0; c0 < e1; c0 += kChunk) {
+      const int ne = (int)((e1 - c0 < kChunk) ? (e1 - c0) : kChunk);
+      __syncthreads();  // previous chunk fully consumed
+      // ---- cooperative staging of ne entries
+      if (VEC) {
+        constexpr int S2 = S / 2;
+        const int M2 = M / 2;
+        for (int i = tid; i < ne * S2; i += 256) {
+          const int ee = i / S2, m2 = i - ee * S2;
+          const int k = a.idx[c0 + ee];
+          reinterpret_cast<double2*>(ye_s)[i] =
+              (m2 < M2) ? reinterpret_cast<const double2*>(a.Ye + (size_t)k * a.ye_stride)[m2] : make_double2(0.0, 0.0);
+        }
+      } else {
+        for (int i = tid; i < ne * S; i += 256) {
+          const int ee = i / S, m = i - ee * S;
+          const int k = a.idx[c0 + ee];
+          ye_s[i] = (m < M) ? a.Ye[(size_t)k * a.ye_stride + m] : 0.0;
+        }
+      }
+      for (int i = tid; i < ne * kBlkCols; i += 256) wt_s[i] = a.wts[(size_t)c0 * kBlkCols + i];
+      if (tid < ne * 4) {
+        const int ee = tid >> 2, q = tid & 3;
+        cf_s[tid] = a.coef[(size_t)a.idx[c0 + ee] * kCoefStride + q];
+      }
+      __syncthreads();
+      // ---- apply the chunk to this wave's 16 rows
+      for (int ee = 0; ee < ne; ++ee) {
+        const double w = live ? wt_s[ee * kBlkCols + r] : 0.0;
+        if (__ballot(w != 0.0) == 0ull) continue;  // none of this wave's rows (dead slab / zero taper)
+        double y[2 * NC];
+        lds_read_row<L, NC>(ye_s + ee * S, j, y);
+        const double* ck = cf_s + ee * 4;
         const double dot = group_dot<L, NC>(x, y);
-        double kc = dot * rM1;           // :95
-        kc = cur.w * kc;                 // :115
-        const double km = kc * cur.c1;   // :119
-        xm = xm + km * cur.c0;           // :130
-        const double kb = cur.c2 * km;   // :136
+        double kc = dot * rM1;         // :95
+        kc = w * kc;                   // :115
+        const double km = kc * ck[1];  // :119
+        xm = xm + km * ck[0];          // :130
+        const double kb = ck[2] * km;  // :136
 #pragma unroll
         for (int c = 0; c < 2 * NC; ++c) x[c] = __builtin_fma(-kb, y[c], x[c]);  // :141
-        cur = nxt;
-#pragma unroll
-        for (int c = 0; c < 2 * NC; ++c) y[c] = yn[c];
       }
     }
     if (live) {
