@@ -28,7 +28,7 @@ def main():
     src, dst, workload, path = sys.argv[1:5]
     os.makedirs(os.path.dirname(dst) or ".", exist_ok=True)
     lines = []
-    stats = glob.glob(os.path.join(src, "stats", "*", "*kernel_stats.csv"))[0]
+    stats = max(glob.glob(os.path.join(src, "stats", "*", "*kernel_stats.csv")), key=os.path.getmtime)
     rows = list(csv.DictReader(open(stats)))
     lines.append("# rocprofv3 --kernel-trace --stats -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline")
     lines.append("# (1 warm-up + 3 timed cycles of the headline workload; durations in microseconds)")
@@ -41,7 +41,7 @@ def main():
                                                   float(r["TotalDurationNs"]) / 1e3, r["Percentage"]))
     pmc = {}
     for ctr, sub in (("FETCH_SIZE", "fetch"), ("WRITE_SIZE", "write")):
-        f = glob.glob(os.path.join(src, sub, "*", "*counter_collection.csv"))
+        f = sorted(glob.glob(os.path.join(src, sub, "*", "*counter_collection.csv")), key=os.path.getmtime, reverse=True)
         if not f:
             continue
         acc = defaultdict(list)
