@@ -55,6 +55,7 @@ def parse_args():
     ap.add_argument("--obs", type=int, default=None, help="override observation count")
     ap.add_argument("--path", default="auto", choices=["auto", "sweep", "transform"])
     ap.add_argument("--obs-batch", type=int, default=None)
+    ap.add_argument("--gram", type=int, default=None, help="Phase-A leader in Gram space (library default if omitted)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-rows", type=int, default=1_000_000)
     ap.add_argument("--cpu-obs", type=int, default=4)
@@ -151,6 +152,8 @@ def main():
     ctx.set_option("path", {"auto": 0, "sweep": 1, "transform": 2}[args.path])
     if args.obs_batch:
         ctx.set_option("obs_batch", args.obs_batch)
+    if args.gram is not None:
+        ctx.set_option("gram", args.gram)
     ctx.set_option("timing", 1)
 
     # ---- synthetic inputs, generated on device per shard -------
@@ -247,6 +250,7 @@ def main():
             "dtype": "f64", "data": "synthetic",
             "config": {"workload": wl["desc"], "rows_per_gpu": rows, "members": M, "obs": P,
                        "loc": loc or "none", "path": path_name, "obs_batch": ctx.get_option("obs_batch"),
+                       "phase_a": {1: "pipeline", 2: "per-batch", 3: "pipeline-gram"}.get(ctx.get_option("phase_a_kind"), "?"),
                        "sharding": "state rows by grid point, obs block replicated, one all-reduce of HX per cycle"},
             "GBps_algorithmic": bytes_per_ob * n_active * world / (elapsed / args.steps) / 1e9,
             "phase_ms": {"obs_phase": obs_ms / args.steps, "state_phase": state_ms / args.steps},

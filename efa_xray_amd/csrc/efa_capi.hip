@@ -79,6 +79,7 @@ struct efa_ctx {
   long obs_batch = 64;
   long path = EFA_PATH_AUTO;
   long timing = 0;
+  long use_gram = 0;       // Gram-space leader for the persistent kernel (falls back to the vector chain)
   long use_pipeline = 1;   // persistent Phase-A kernel when it applies (else per-batch kernels)
   long spin_limit = 4000000;
   long pipe_debug = 0;
@@ -257,22 +258,29 @@ int obs_phase(efa_ctx* c, int M, long P, double* ym_dev, double* Yp_dev, const d
       EFA_HIP(hipMemsetAsync(c->dbg.p, 0, (size_t)P * 8 * sizeof(unsigned long long), s));
       pa.dbg = c->dbg.as<unsigned long long>();
     }
-    EFA_HIP(launch_pipeline(pa, s));
-    int st[2] = {0, 0};
-    EFA_HIP(hipMemcpyAsync(st, c->status.p, sizeof(st), hipMemcpyDeviceToHost, s));
-    EFA_HIP(hipStreamSynchronize(s));
-    if (st[0] == 0 && st[1] == 0) {
-      done_by_pipeline = true;
-      c->ye_ptr = reinterpret_cast<const double*>(c->traj.p);
-      c->ye_stride = TS;
-      c->phase_a_kind = 1;
-    }
-    else {
-      // a bounded spin expired (co-residency lost?): workgroups that had already finished may
-      // have written their rows back, so restore the obs block before the per-batch kernels
-      EFA_HIP(hipMemcpyAsync(Yw, Yp_dev, (size_t)P * M * sizeof(double), hipMemcpyDeviceToDevice, s));
-      EFA_HIP(hipMemcpyAsync(ymw, ym_dev, dP, hipMemcpyDeviceToDevice, s));
-      if (carry_T) EFA_HIP(launch_set_identity(M, Yw + (size_t)P * M, ymw + P, s));
+    // attempt 0: Gram-space leader (option "gram"); attempt 1: vector-chain pipeline.  A failed
+    // attempt (bounded spin expired, or the Gram downdate's cancellation guard) may have let
+    // finished workgroups write their rows back, so the obs block is restored before the next.
+    for (int attempt = (c->use_gram && pipeline_gram_supported(M, R, loc_mode)) ? 0 : 1; attempt < 2 && !done_by_pipeline;
+         ++attempt) {
+      EFA_HIP(attempt == 0 ? launch_pipeline_gram(pa, s) : launch_pipeline(pa, s));
+      int st[2] = {0, 0};
+      EFA_HIP(hipMemcpyAsync(st, c->status.p, sizeof(st), hipMemcpyDeviceToHost, s));
+      EFA_HIP(hipStreamSynchronize(s));
+      if (st[0] == 0 && st[1] == 0) {
+        done_by_pipeline = true;
+        c->ye_ptr = reinterpret_cast<const double*>(c->traj.p);
+        c->ye_stride = TS;
+        c->phase_a_kind = (attempt == 0) ? 3 : 1;
+      } else {
+        EFA_HIP(hipMemcpyAsync(Yw, Yp_dev, (size_t)P * M * sizeof(double), hipMemcpyDeviceToDevice, s));
+        EFA_HIP(hipMemcpyAsync(ymw, ym_dev, dP, hipMemcpyDeviceToDevice, s));
+        if (carry_T) EFA_HIP(launch_set_identity(M, Yw + (size_t)P * M, ymw + P, s));
+        if (attempt == 0) {
+          EFA_HIP(launch_fill_u64(c->traj.as<unsigned long long>(), (size_t)P * TS, kTrajSentinel, s));
+          EFA_HIP(hipMemsetAsync(c->status.p, 0, 2 * sizeof(int), s));
+        }
+      }
     }
   }
   if (!done_by_pipeline) {
@@ -610,6 +618,8 @@ int efa_ctx_set_option(efa_ctx* c, const char* key, long value) {
     c->path = value;
   } else if (!strcmp(key, "timing")) {
     c->timing = value ? 1 : 0;
+  } else if (!strcmp(key, "gram")) {
+    c->use_gram = value ? 1 : 0;
   } else if (!strcmp(key, "pipeline")) {
     c->use_pipeline = value ? 1 : 0;
   } else if (!strcmp(key, "gc_onepass")) {
@@ -634,6 +644,7 @@ int efa_ctx_get_option(efa_ctx* c, const char* key, long* value) {
   if (!strcmp(key, "obs_batch")) *value = c->obs_batch;
   else if (!strcmp(key, "path")) *value = c->path;
   else if (!strcmp(key, "timing")) *value = c->timing;
+  else if (!strcmp(key, "gram")) *value = c->use_gram;
   else if (!strcmp(key, "pipeline")) *value = c->use_pipeline;
   else if (!strcmp(key, "phase_a_kind")) *value = c->phase_a_kind;
   else if (!strcmp(key, "pipe_dbg_addr")) *value = (long)reinterpret_cast<uintptr_t>(c->dbg.p);

@@ -1,0 +1,698 @@
+// Persistent Phase-A pipeline, Gram-space leader ("k_pipe_gram").
+//
+// Same launch structure and inter-workgroup protocol as efa_pipeline.hip (one workgroup per 64
+// obs rows, rows resident in registers, sentinel-validated agent-scope trajectory records), but
+// the LEADER no longer carries vectors on its serial chain.  In efa_pipeline.hip every step of
+// the chain contains an M-long LDS read, a dot product with a cross-lane reduction, the gain
+// scalars and an M-long LDS write (~2400 cycles).  Here, when a workgroup's turn comes:
+//
+//   1. its 64 rows are written once to an LDS tile and G = Y Y^T (the 64 x 64 matrix of their
+//      dot products) is formed on the matrix cores (v_mfma_f64_16x16x4_f64, ~3 us);
+//   2. ONE "pivot" wave runs the serial recurrence in Gram space, lane j = row j: for ob k
+//         var_k   = G_kk/M - mean_k^2                       (np.var, ddof 0: ensrf.py:69)
+//         kmat_j  = w_jk * G_kj/(M-1) / kdenom_k            (:95,:115,:119) for all 64 rows at once
+//         kb_j    = beta_k * kmat_j                         (:136)
+//         G_ij   -= kb_j G_ki + kb_i (G_kj - kb_j G_kk)     (what y_i -= kb_i ye_k does to the dots)
+//      no dot products, no reductions, no vectors: lane k's values are fetched with v_readlane.
+//      Two helper waves apply the rank-one downdate to the rows that become pivots later;
+//   3. the four vector waves follow behind: with kmat_i known, a step is a pure axpy
+//      y_i -= kb_i ye_k, and ye_k itself is just row k after its own axpys;
+//   4. the loader wave forwards (ye_k from the vector ring, scalars from the pivot wave) to
+//      global memory for the other workgroups, which consume them exactly as before.
+//
+// The dot products of a block are thus taken from ONE fresh Gram matrix per 64 obs and downdated
+// in between; if a pivot's G_kk has shrunk below 1e-3 of its value at the start of the block
+// (the downdate may then have lost more than three digits) the kernel bails out through the
+// usual abort word and the host re-runs Phase A with efa_pipeline.hip.
+#include <type_traits>
+
+#include "efa_device.h"
+#include "efa_internal.h"
+#include "efa_rows.h"
+
+namespace efa {
+namespace {
+
+typedef unsigned long long u64;
+typedef double v4f64 __attribute__((ext_vector_type(4)));
+
+constexpr int kVW = 4;        // vector waves (quad per row, one per SIMD)
+constexpr int kGT = 512;      // threads: 4 vector + pivot + 2 helpers + loader
+constexpr int PLg = kPipeLanes;  // lanes per row: same record layout as efa_pipeline.hip
+constexpr int kRingG = 16;    // LDS ring slots for ye rows
+constexpr int kPollG = 4;
+constexpr int kRowsWG = kPipeRowsPerWG;  // 64
+static_assert(PLg == 4 && kRowsWG == 64, "layout assumptions of the Gram kernel");
+
+enum { cReady = 0, cBail = 1, cSReady = 2, cFwd = 3, cProg = 4, cHProg = 8 };
+
+__device__ __forceinline__ u64 g_traj_load(const u64* p) {
+  return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ void g_traj_store(u64* p, double v) {
+  __hip_atomic_store(p, (u64)__double_as_longlong(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ int g_ctl_lane(const int* p) {
+  const int v = __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+  asm volatile("" ::: "memory");
+  return v;
+}
+__device__ __forceinline__ int g_ctl(const int* p) { return __builtin_amdgcn_readfirstlane(g_ctl_lane(p)); }
+__device__ __forceinline__ void g_ctl_set(int* p, int v) {
+  asm volatile("" ::: "memory");
+  __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+__device__ __forceinline__ double g_rsq(double a) {  // see efa_pipeline.hip: one Newton step suffices
+  const double q = __builtin_amdgcn_rsq(a);
+  const double e = __builtin_fma(-a * q, q, 1.0);
+  const double p = __builtin_fma(0.375, e, 0.5);
+  return __builtin_fma(q * e, p, q);
+}
+__device__ __forceinline__ double g_rcp(double b) {
+  const double r = __builtin_amdgcn_rcp(b);
+  const double e = __builtin_fma(-b, r, 1.0);
+  return __builtin_fma(r, __builtin_fma(e, e, e), r);
+}
+__device__ __forceinline__ double rl(double v, int lane) {  // value held by `lane` (wave-uniform index)
+  const int lo = __builtin_amdgcn_readlane(__double2loint(v), lane);
+  const int hi = __builtin_amdgcn_readlane(__double2hiint(v), lane);
+  return __hiloint2double(hi, lo);
+}
+
+template <int NC>
+struct GramShape {
+  static constexpr int PAD = 2 * PLg * NC;
+  static constexpr int TS = PAD + kTrajScalars;
+  static constexpr int SP = PAD + ((2 - PAD % 32) + 32) % 32;  // tile row stride == 2 (mod 32): conflict-free operand reads
+  static constexpr int UREG = (kRowsWG * SP > kRowsWG * (2 * kRowsWG + 8)) ? kRowsWG * SP : kRowsWG * (2 * kRowsWG + 8);
+  static size_t lds_bytes(bool gc) {
+    return ((size_t)kRingG * TS + kRowsWG * kRowsWG + UREG + 2 * kRowsWG + (gc ? kRowsWG * kRowsWG : 0)) * sizeof(double) +
+           16 * sizeof(int);
+  }
+};
+
+template <int NC>
+__global__ __launch_bounds__(kGT) void k_pipe_gram(const PipeArgs a) {
+  using Sh = GramShape<NC>;
+  constexpr int PAD = Sh::PAD, TS = Sh::TS, SP = Sh::SP, UREG = Sh::UREG;
+  constexpr int EPL = (TS + 63) / 64;
+  constexpr int NMR = (PAD + 63) / 64;  // registers per row in the block's lane = member layout
+  extern __shared__ __align__(16) double lds[];
+  double* ring = lds;                          // [kRingG][TS]   ye rows (+ scalars in follower mode)
+  double* G_s = ring + kRingG * TS;            // [64][64]       Gram matrix of the block
+  double* U = G_s + kRowsWG * kRowsWG;         // union: Yt[64][SP]  then  {g, kb}[64][64], sc[64][8]
+  double* pm = U + UREG;                       // [2][64]        parked row means / obs-space means
+  double* tw_s = pm + 2 * kRowsWG;             // [64][64]       taper corner (GC only)
+  int* ctl = reinterpret_cast<int*>(tw_s + (a.loc_mode != 0 ? kRowsWG * kRowsWG : 0));  // [16]
+  double* Yt = U;
+  // per-step records of the pivot wave.  kmat of step kk goes into row kk of G_s: that row is dead by
+  // then (the pivot holds it in registers, and its helper finished loading its rows before handing it over)
+  double* s_km = G_s;
+  double2* s_gk = reinterpret_cast<double2*>(U);  // [step][row] = {G_kj, kb_j}
+  double* s_sc = U + 2 * kRowsWG * kRowsWG;
+
+  const int tid = threadIdx.x;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
+  const int M = a.M;
+  const long P = a.P, R = a.R;
+  const long own0 = (long)blockIdx.x * kRowsWG;
+  const long own1 = (own0 + kRowsWG < P) ? own0 + kRowsWG : (own0 < P ? P : own0);
+  const int nb = (int)(own1 - own0);  // obs this workgroup leads (0: it only follows)
+  const bool leads = nb > 0;
+  const double rM1 = 1.0 / (double)(M - 1);
+  const double invM = 1.0 / (double)M;
+
+  if (tid < 16) ctl[tid] = (tid >= cProg) ? -1 : (tid == cFwd ? (int)(own0 - 1) : 0);
+  __syncthreads();
+
+#define EFA_GSTAMP(cond, kidx, slot)                                                                          \
+  do {                                                                                                          \
+    if (a.dbg != nullptr && (cond)) a.dbg[(size_t)(kidx) * 8 + (slot)] = __builtin_amdgcn_s_memtime();       \
+  } while (0)
+  long budget = a.spin_limit;
+  int polls = 0;
+  auto give_up = [&]() {
+    __hip_atomic_store(a.status, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(a.status + 1, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    g_ctl_set(&ctl[cBail], 1);
+  };
+  // wait until *word > thr; false if the kernel is being abandoned
+  auto wait_gt = [&](const int* word, int thr, bool doze) {
+    while (g_ctl(word) <= thr) {
+      if ((++polls & 15) == 0) {
+        if (g_ctl(&ctl[cBail]) != 0) return false;
+        budget -= 16;
+        if (budget <= 0) {
+          give_up();
+          return false;
+        }
+      }
+      if (doze) __builtin_amdgcn_s_sleep(1);
+    }
+    return true;
+  };
+
+  auto wait2_gt = [&](const int* wa, int ta, const int* wb, int tb, bool doze) {  // both words in one LDS round trip
+    for (;;) {
+      const int va = g_ctl_lane(wa), vb = g_ctl_lane(wb);
+      if (__builtin_amdgcn_readfirstlane(va) > ta && __builtin_amdgcn_readfirstlane(vb) > tb) return true;
+      if ((++polls & 15) == 0) {
+        if (g_ctl(&ctl[cBail]) != 0) return false;
+        budget -= 16;
+        if (budget <= 0) {
+          give_up();
+          return false;
+        }
+      }
+      if (doze) __builtin_amdgcn_s_sleep(1);
+    }
+  };
+
+  // G = Y Y^T for the pivot rows, every wave takes two 16 x 16 tiles (between the block-start barriers)
+  auto form_gram = [&]() {
+    const int I = wave >> 1, J0 = (wave & 1) * 2;
+    if (16 * I < nb) {
+      v4f64 acc0 = {0.0, 0.0, 0.0, 0.0}, acc1 = {0.0, 0.0, 0.0, 0.0};
+      const double* pa = Yt + (size_t)(16 * I + (lane & 15)) * SP + (lane >> 4);
+      const double* pb0 = Yt + (size_t)(16 * J0 + (lane & 15)) * SP + (lane >> 4);
+      const double* pb1 = pb0 + 16 * SP;
+      for (int s = 0; s < PAD / 4; ++s) {
+        const double av = pa[4 * s], b0 = pb0[4 * s], b1 = pb1[4 * s];
+        acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(av, b0, acc0, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(av, b1, acc1, 0, 0, 0);
+      }
+      // D layout (probed, tools/mfma_probe.hip): row = 4 v + lane/16, col = lane%16
+#pragma unroll
+      for (int v = 0; v < 4; ++v) {
+        const int gi = 16 * I + 4 * v + (lane >> 4);
+        G_s[gi * kRowsWG + 16 * J0 + (lane & 15)] = acc0[v];
+        G_s[gi * kRowsWG + 16 * (J0 + 1) + (lane & 15)] = acc1[v];
+      }
+    }
+  };
+
+  // ======================================================================================
+  // wave 7: loader (follower mode) / forwarder (leader mode)
+  // ======================================================================================
+  if (wave == 7) {
+    long next = 0;
+    bool failed = false;
+    int barriers_left = leads ? 3 : 0;
+    while (next < P && !failed) {
+      if (leads && next == own0) {
+        __syncthreads();  // B1: the vector waves have parked their rows in the tile
+        form_gram();
+        if (a.loc_mode != 0) {  // this block's 64 x 64 corner of the obs-obs taper
+          for (int i = lane; i < kRowsWG * kRowsWG; i += 64) {
+            const long kg = own0 + (i >> 6), rg = own0 + (i & 63);
+            tw_s[i] = (kg < P && rg < R) ? a.tw[(size_t)kg * R + rg] : 1.0;
+          }
+        }
+        __syncthreads();  // B2: G and the taper corner are complete
+        barriers_left = 1;
+        for (long f = own0; f < own1 && !failed; ++f) {
+          if (!wait2_gt(&ctl[cReady], (int)f, &ctl[cSReady], (int)(f - own0), true)) {
+            failed = true;
+            break;
+          }
+          const double* slot = ring + (size_t)(f % kRingG) * TS;
+          const double* sc = s_sc + (size_t)(f - own0) * 8;
+          u64* rec = a.traj + (size_t)f * TS;
+#pragma unroll
+          for (int e = 0; e < EPL; ++e) {
+            const int idx = lane + 64 * e;
+            if (idx < TS) g_traj_store(rec + idx, idx < PAD ? slot[idx] : sc[idx - PAD]);
+          }
+          if (lane == 0) g_ctl_set(&ctl[cFwd], (int)f);
+          EFA_GSTAMP(lane == 0, f, 7);
+        }
+        __syncthreads();  // B3: done with the pivot's records
+        barriers_left = 0;
+        next = own1;
+        continue;
+      }
+      const long limit = (next < own0) ? ((own0 < P) ? own0 : P) : P;
+      const int nrec = (int)((limit - next < kPollG) ? (limit - next) : kPollG);
+      u64 v[kPollG][EPL];
+#pragma unroll
+      for (int d = 0; d < kPollG; ++d) {
+        const long kk = next + ((d < nrec) ? d : nrec - 1);
+        const u64* rec = a.traj + (size_t)kk * TS;
+#pragma unroll
+        for (int e = 0; e < EPL; ++e) {
+          const int idx = lane + 64 * e;
+          v[d][e] = g_traj_load(rec + (idx < TS ? idx : TS - 1));
+        }
+      }
+      int cnt = 0;
+#pragma unroll
+      for (int d = 0; d < kPollG; ++d) {
+        bool ok = true;
+#pragma unroll
+        for (int e = 0; e < EPL; ++e) ok = ok && (v[d][e] != kTrajSentinel);
+        if (cnt == d && d < nrec && __all(ok)) cnt = d + 1;
+      }
+      if (cnt == 0) {
+        if (--budget <= 0 || __hip_atomic_load(a.status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) failed = true;
+        __builtin_amdgcn_s_sleep(2);
+        continue;
+      }
+      const long need = next + cnt - 1 - kRingG;  // slots are recycled only once every vector wave consumed them
+      if (need >= 0) {
+        for (;;) {
+          int mn = g_ctl_lane(&ctl[cProg + (lane & 3)]);
+          mn = min(mn, __builtin_amdgcn_mov_dpp(mn, 0xB1, 0xF, 0xF, true));
+          mn = min(mn, __builtin_amdgcn_mov_dpp(mn, 0x4E, 0xF, 0xF, true));
+          if (__builtin_amdgcn_readfirstlane(mn) >= (int)need) break;
+          if (--budget <= 0 || g_ctl(&ctl[cBail]) != 0) {
+            failed = true;
+            break;
+          }
+        }
+        if (failed) break;
+      }
+#pragma unroll
+      for (int d = 0; d < kPollG; ++d) {
+        if (d < cnt) {
+          double* slot = ring + (size_t)((next + d) % kRingG) * TS;
+#pragma unroll
+          for (int e = 0; e < EPL; ++e) {
+            const int idx = lane + 64 * e;
+            if (idx < TS) slot[idx] = __longlong_as_double((long long)v[d][e]);
+          }
+        }
+      }
+      next += cnt;
+      if (lane == 0) g_ctl_set(&ctl[cReady], (int)next);
+    }
+    if (failed && lane == 0) give_up();
+    for (; barriers_left > 0; --barriers_left) __syncthreads();  // never leave the others at a barrier
+    return;
+  }
+
+  // ======================================================================================
+  // wave 4 (pivot) and waves 5, 6 (helpers): the Gram-space recurrence of this workgroup's block
+  // ======================================================================================
+  if (wave >= kVW) {
+    if (!leads) return;
+    __syncthreads();  // B1
+    form_gram();
+    __syncthreads();  // B2
+    if (wave == kVW) {
+      // ---------------- pivot wave: lane j <-> row j of the workgroup ----------------
+      const long obj = own0 + lane;
+      const bool is_ob = lane < nb;
+      double mu = pm[lane], xmv = pm[kRowsWG + lane];
+      const double val = is_ob ? a.ob_value[obj] : 0.0;
+      const double err = is_ob ? a.ob_error[obj] : 1.0;
+      const double sq = sqrt(err);
+      const int asmf = is_ob ? (a.ob_assim[obj] != 0 ? 1 : 0) : 0;
+      const double d0 = is_ob ? G_s[lane * kRowsWG + lane] : 1.0;
+      double o_pm = 0.0, o_pv = 0.0, o_in = 0.0, o_rd = 0.0, o_be = 0.0, o_qm = 0.0, o_qv = 0.0;
+      bool o_done = false, bailed = false;
+      double g = G_s[lane];             // row 0
+      double g1 = G_s[kRowsWG + lane];  // row 1
+      __builtin_amdgcn_s_setprio(3);
+      for (int kk = 0; kk < nb; ++kk) {
+        EFA_GSTAMP(lane == 0, own0 + kk, 0);
+        const int f_early = g_ctl_lane(&ctl[cHProg + (kk & 1)]);  // flag first, then the row (LDS keeps the order)
+        double r2 = G_s[((kk + 2 < kRowsWG) ? kk + 2 : 0) * kRowsWG + lane];
+        const double Gkk = rl(g, kk), muk = rl(mu, kk), xmk = rl(xmv, kk);
+        const double valk = rl(val, kk), errk = rl(err, kk), sqk = rl(sq, kk);
+        const bool act = __builtin_amdgcn_readlane(asmf, kk) != 0;
+        const double var = __builtin_fma(Gkk, invM, -(muk * muk));   // np.var, ddof = 0 (:69)
+        if (act && !(Gkk > 1e-3 * rl(d0, kk))) {  // the downdate may have cancelled: leave it to efa_pipeline.hip
+          if (lane == 0) give_up();
+          bailed = true;
+          break;
+        }
+        const double innov = valk - xmk;                              // :85
+        const double kdenom = var + errk;                             // :91
+        const double q = g_rsq(kdenom);
+        const double rden = q * q;
+        const double beta = g_rcp(1.0 + sqk * q);                     // :135
+        double kc = g * rM1;                                          // :95
+        if (a.loc_mode != 0) kc = tw_s[kk * kRowsWG + lane] * kc;     // :115
+        const double km = act ? kc * rden : 0.0;                      // :119
+        const double kb = beta * km;                                  // :136
+        s_km[kk * kRowsWG + lane] = km;
+        s_gk[kk * kRowsWG + lane] = make_double2(g, kb);
+        if (lane == 0) {
+          double2* sc = reinterpret_cast<double2*>(s_sc + (size_t)kk * 8);
+          sc[0] = make_double2(xmk, muk);
+          sc[1] = make_double2(innov, rden);
+          sc[2] = make_double2(beta, act ? 1.0 : 0.0);
+          sc[3] = make_double2(var, Gkk);
+          g_ctl_set(&ctl[cSReady], kk + 1);
+        }
+        EFA_GSTAMP(lane == 0, own0 + kk, 1);
+        if (lane == kk) {
+          o_pm = xmk;   // :66
+          o_pv = var;   // :70
+          o_in = innov;
+          o_rd = rden;
+          o_be = beta;
+        }
+        xmv = xmv + km * innov;                                       // :130
+        mu = __builtin_fma(-kb, muk, mu);
+        if (lane == kk && act) {
+          const double f = 1.0 - kb;  // the ob's own row is scaled by (1 - kb)  (:144-149)
+          o_qv = (f * f) * var;
+          o_qm = xmv;
+          o_done = true;
+        }
+        if (kk + 1 < nb) {
+          // g1 = row kk+1 through step kk-1; row kk+2 through step kk-1 comes from its helper (handed
+          // over through G_s during the helper's step kk-1, read speculatively at the top of this step)
+          const double t = g - kb * Gkk;
+          const double gi = rl(g, kk + 1), ai = rl(kb, kk + 1);
+          const double gnew = g1 - (kb * gi + ai * t);
+          if (kk + 2 < nb) {
+            if (kk >= 1 && __builtin_amdgcn_readfirstlane(f_early) < kk + 2) {
+              const int* flag = &ctl[cHProg + (kk & 1)];
+              for (;;) {
+                const int f = g_ctl_lane(flag);
+                r2 = G_s[(kk + 2) * kRowsWG + lane];
+                if (__builtin_amdgcn_readfirstlane(f) >= kk + 2) break;
+                if ((++polls & 15) == 0) {
+                  budget -= 16;
+                  if (g_ctl(&ctl[cBail]) != 0) bailed = true;
+                  else if (budget <= 0) {
+                    if (lane == 0) give_up();
+                    bailed = true;
+                  }
+                  if (bailed) break;
+                }
+              }
+              if (bailed) break;
+            }
+            const double gi2 = rl(g, kk + 2), ai2 = rl(kb, kk + 2);
+            g1 = r2 - (kb * gi2 + ai2 * t);
+          }
+          g = gnew;
+          EFA_GSTAMP(lane == 0, own0 + kk, 2);
+        }
+      }
+      pm[kRowsWG + lane] = xmv;  // obs-space means of all 64 rows after the block, back to the vector waves
+      __builtin_amdgcn_s_setprio(0);
+      __syncthreads();  // B3
+      if (!bailed && g_ctl(&ctl[cBail]) == 0 && is_ob) {
+        a.prior_mean[obj] = o_pm;
+        a.prior_var[obj] = o_pv;
+        double* ck = a.coef + (size_t)obj * kCoefStride;
+        ck[0] = asmf ? o_in : 0.0;
+        ck[1] = asmf ? o_rd : 0.0;
+        ck[2] = asmf ? o_be : 0.0;
+        ck[3] = asmf ? 1.0 : 0.0;
+        a.assimilated[obj] = o_done ? 1 : 0;  // :74-76, :149
+        if (o_done) {
+          a.post_mean[obj] = o_qm;
+          a.post_var[obj] = o_qv;
+        }
+      }
+      return;
+    }
+    // ---------------- helper waves: rows that become pivots later ----------------
+    // helper h keeps the 32 rows of its parity in registers (lane = column) and applies each step's
+    // rank-one downdate to those at least three rows ahead of the pivot; row kk+3 is handed to the
+    // pivot wave through G_s during step kk, a full step before the pivot needs it (the pivot applies
+    // the last two steps to it itself), so only the helpers' throughput matters, not their latency
+    const int h = wave - kVW - 1;  // 0, 1
+    __builtin_amdgcn_s_setprio(2);
+    double gr[kRowsWG / 2];
+#pragma unroll
+    for (int r = 0; r < kRowsWG / 2; ++r) gr[r] = (2 * r + h >= 3) ? G_s[(2 * r + h) * kRowsWG + lane] : 0.0;
+    auto downdate = [&](const double2* rec, double kb, double t, int kk, auto half) {
+      constexpr int H = decltype(half)::value;  // rows 32 H .. 32 H + 31, sixteen of them here
+      double2 ga[16];  // {G_ki, kb_i} of the rows: uniform-address LDS reads, all in flight together
+#pragma unroll
+      for (int q = 0; q < 16; ++q) ga[q] = rec[32 * H + 2 * q + h];
+#pragma unroll
+      for (int q4 = 0; q4 < 4; ++q4) {  // four rows at a time, the two dependent FMAs of a row kept apart
+#pragma unroll
+        for (int q = 4 * q4; q < 4 * q4 + 4; ++q) gr[16 * H + q] = __builtin_fma(-kb, ga[q].x, gr[16 * H + q]);
+#pragma unroll
+        for (int q = 4 * q4; q < 4 * q4 + 4; ++q) gr[16 * H + q] = __builtin_fma(-ga[q].y, t, gr[16 * H + q]);
+      }
+      if (kk + 3 >= 32 * H && kk + 3 < 32 * H + 32 && ((kk + 3) & 1) == h) {  // the hand-over row is one of these
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+          const int i = 32 * H + 2 * q + h;
+          if (i == kk + 3) G_s[i * kRowsWG + lane] = gr[16 * H + q];
+        }
+        if (lane == 0) g_ctl_set(&ctl[cHProg + h], kk + 3);
+        EFA_GSTAMP(lane == 0 && !(a.debug & 8), own0 + kk, 6);
+      }
+    };
+    for (int kk = 0; kk + 3 < nb; ++kk) {
+      if (!wait_gt(&ctl[cSReady], kk, false)) break;
+      EFA_GSTAMP(lane == 0 && h == 0 && (a.debug & 8), own0 + kk, 3);
+      const double2* rec = s_gk + kk * kRowsWG;
+      const double2 own = rec[lane];
+      const double Gkk = s_sc[kk * 8 + 7];
+      const double kb = own.y;
+      const double t = own.x - kb * Gkk;
+      EFA_GSTAMP(lane == 0 && h == ((kk + 1) & 1) && !(a.debug & 8), own0 + kk, 5);
+      EFA_GSTAMP(lane == 0 && h == 0 && (a.debug & 8), own0 + kk, 4);
+      // rows behind the pivot may be updated too (their registers are dead)
+      if (kk + 3 < 32) downdate(rec, kb, t, kk, std::integral_constant<int, 0>());
+      EFA_GSTAMP(lane == 0 && h == 0 && (a.debug & 8), own0 + kk, 5);
+      downdate(rec, kb, t, kk, std::integral_constant<int, 1>());
+      EFA_GSTAMP(lane == 0 && h == 0 && (a.debug & 8), own0 + kk, 6);
+    }
+    __syncthreads();  // B3
+    return;
+  }
+
+  // ======================================================================================
+  // waves 0-3: vector waves, rows in registers for the whole kernel
+  // ======================================================================================
+  const int j = lane & (PLg - 1);
+  const int grp = lane / PLg;
+  const int i_loc = wave + kVW * grp;  // consecutive obs in different waves
+  const long row = own0 + i_loc;
+  const bool live = row < R;
+  const bool vec = (M % 2 == 0);
+  double x[2 * NC];
+  double xm = 0.0;
+  if (live) {
+    if (vec) load_row<PLg, NC, true>(a.Yp + (size_t)row * M, M, j, x);
+    else load_row<PLg, NC, false>(a.Yp + (size_t)row * M, M, j, x);
+    xm = a.ym[row];
+  } else {
+#pragma unroll
+    for (int c = 0; c < 2 * NC; ++c) x[c] = 0.0;
+  }
+  const bool use_tw = (a.loc_mode != 0) && live;
+  double wq0 = 1.0, wq1 = 1.0;  // GC taper of ob k against this row, prefetched two obs ahead (follower mode)
+  auto prime_tw = [&](long k0) {
+    if (use_tw) {
+      wq0 = (k0 < P) ? a.tw[(size_t)k0 * R + row] : 1.0;
+      wq1 = (k0 + 1 < P) ? a.tw[(size_t)(k0 + 1) * R + row] : 1.0;
+    }
+  };
+  prime_tw(0);
+  int barriers_left = leads ? 3 : 0;
+  bool bailed = false;
+  auto min_prog = [&]() {  // least-advanced consumer of the ring: the 4 vector waves and the forwarder
+    int mn = min(g_ctl_lane(&ctl[cProg + j]), g_ctl_lane(&ctl[cFwd]));
+    mn = min(mn, __builtin_amdgcn_mov_dpp(mn, 0xB1, 0xF, 0xF, true));
+    mn = min(mn, __builtin_amdgcn_mov_dpp(mn, 0x4E, 0xF, 0xF, true));
+    return __builtin_amdgcn_readfirstlane(mn);
+  };
+  long k = 0;
+  while (k < P && !bailed) {
+    if (leads && k == own0) {
+      // ---------------- this workgroup's block ----------------
+#pragma unroll
+      for (int c = 0; c < NC; ++c)
+        *reinterpret_cast<double2*>(Yt + (size_t)i_loc * SP + 2 * PLg * c + 2 * j) = make_double2(x[2 * c], x[2 * c + 1]);
+      const double rmean = group_rowsum<PLg, NC>(x) * invM;
+      if (j == 0) {
+        pm[i_loc] = rmean;
+        pm[kRowsWG + i_loc] = xm;
+      }
+      __syncthreads();  // B1: tile and parked means complete
+      form_gram();
+      // For the block the rows change layout: "lane = member".  Wave w re-reads the 16 rows it has
+      // just parked (rows 4 q + w) with lane m holding members m and 64 + m.  An axpy then needs ye as
+      // two per-lane values instead of the 13 quad-replicated ds_read_b128 of the follower layout:
+      // the LDS pipe, which all eight waves share, is what bounds the block otherwise.
+      // Slot q of wave w holds row 4 ((q + rot) & 15) + w: the slots are rotated each time the wave has
+      // published a row, so that the next row this wave publishes is always in slot 0 (static registers).
+      double xr[16][NMR];
+#pragma unroll
+      for (int q = 0; q < 16; ++q)
+#pragma unroll
+        for (int e = 0; e < NMR; ++e) xr[q][e] = Yt[(size_t)(4 * q + wave) * SP + 64 * e + lane];
+      __syncthreads();  // B2: G complete; the tile region now belongs to the pivot wave's records
+      barriers_left = 1;
+      int rot = 0;
+      auto rotate = [&]() {
+        double t0[NMR];
+#pragma unroll
+        for (int e = 0; e < NMR; ++e) t0[e] = xr[0][e];
+#pragma unroll
+        for (int q = 0; q < 15; ++q)
+#pragma unroll
+          for (int e = 0; e < NMR; ++e) xr[q][e] = xr[q + 1][e];
+#pragma unroll
+        for (int e = 0; e < NMR; ++e) xr[15][e] = t0[e];
+        rot = (rot + 1) & 15;
+      };
+      auto publish_slot0 = [&](long kn) {  // slot 0 IS ye of ob kn
+        double* slot = ring + (size_t)(kn % kRingG) * TS;
+#pragma unroll
+        for (int e = 0; e < NMR; ++e)
+          if (64 * e + lane < PAD) slot[64 * e + lane] = xr[0][e];
+        if (lane == 0) g_ctl_set(&ctl[cReady], (int)(kn + 1));
+      };
+      if (wave == 0) {
+        publish_slot0(own0);
+        rotate();
+      }
+      for (int kk = 0; kk < nb; ++kk) {
+        const long kg = own0 + kk;
+        const int nu = kk + 1;                                          // the row that is ye of the next ob
+        const bool mine = ((nu & (kVW - 1)) == wave) && nu < nb;        // ... is held by this wave (in slot 0)
+        if (!wait2_gt(&ctl[cReady], (int)kg, &ctl[cSReady], kk, !mine)) {
+          bailed = true;
+          break;
+        }
+        EFA_GSTAMP(mine && lane == 0 && !(a.debug & 8), kg, 3);
+        const double* slot = ring + (size_t)(kg % kRingG) * TS;
+        double y[NMR];
+#pragma unroll
+        for (int e = 0; e < NMR; ++e) y[e] = slot[64 * e + lane];
+        const double kmv = s_km[kk * kRowsWG + lane];                   // lane = row of the workgroup
+        const double beta = s_sc[kk * 8 + 4];
+        if (lane == 0) g_ctl_set(&ctl[cProg + wave], (int)kg);
+        const double kbv = beta * kmv;                                  // :136
+        {
+          const double kb = rl(kbv, 4 * rot + wave);
+#pragma unroll
+          for (int e = 0; e < NMR; ++e) xr[0][e] = __builtin_fma(-kb, y[e], xr[0][e]);  // :141
+        }
+        if (mine) {  // the chain: publish the next ye before the other fifteen rows are touched
+          if ((nu & 3) == 0) {  // recycling guard, amortised over four records
+            while (min_prog() < (int)(kg + 1 + 3 - kRingG)) {
+              if (g_ctl(&ctl[cBail]) != 0 || --budget <= 0) {
+                bailed = true;
+                break;
+              }
+            }
+            if (bailed) break;
+          }
+          publish_slot0(kg + 1);
+          EFA_GSTAMP(lane == 0 && !(a.debug & 8), kg, 4);
+        }
+#pragma unroll
+        for (int q = 1; q < 16; ++q) {
+          const double kb = rl(kbv, 4 * ((q + rot) & 15) + wave);
+#pragma unroll
+          for (int e = 0; e < NMR; ++e) xr[q][e] = __builtin_fma(-kb, y[e], xr[q][e]);  // :141
+        }
+        if (mine) rotate();
+      }
+      __syncthreads();  // B3: every wave is done with the pivot's records; the tile region is free again
+      barriers_left = 0;
+      if (bailed) break;
+      // back to the follower layout through the tile (each wave reads only rows it wrote itself)
+#pragma unroll
+      for (int q = 0; q < 16; ++q)
+#pragma unroll
+        for (int e = 0; e < NMR; ++e)
+          if (64 * e + lane < PAD) Yt[(size_t)(4 * ((q + rot) & 15) + wave) * SP + 64 * e + lane] = xr[q][e];
+#pragma unroll
+      for (int c = 0; c < NC; ++c) {
+        const double2 v = *reinterpret_cast<const double2*>(Yt + (size_t)i_loc * SP + 2 * PLg * c + 2 * j);
+        x[2 * c] = v.x;
+        x[2 * c + 1] = v.y;
+      }
+      xm = pm[kRowsWG + i_loc];  // the pivot wave carried the obs-space means through the block (:130)
+      k = own1;
+      prime_tw(k);
+      continue;
+    }
+    // ---------------- follower step: consume record k from the ring ----------------
+    if (!wait_gt(&ctl[cReady], (int)k, true)) {
+      bailed = true;
+      break;
+    }
+    const double* slot = ring + (size_t)(k % kRingG) * TS;
+    double y[2 * NC];
+    lds_read_row<PLg, NC>(slot, j, y);
+    const double2 s23 = *reinterpret_cast<const double2*>(slot + PAD + 2);  // innov, rden
+    const double2 s45 = *reinterpret_cast<const double2*>(slot + PAD + 4);  // beta, active
+    if (lane == 0) g_ctl_set(&ctl[cProg + wave], (int)k);
+    const double w = wq0;
+    wq0 = wq1;
+    if (use_tw) wq1 = a.tw[(size_t)((k + 2 < P) ? k + 2 : P - 1) * R + row];
+    if (__builtin_amdgcn_readfirstlane((int)(s45.y != 0.0)) != 0) {
+      const double dot = group_dot<PLg, NC>(x, y);
+      double kc = dot * rM1;                              // :95
+      if (a.loc_mode != 0) kc = (live ? w : 0.0) * kc;    // :115
+      const double km = kc * s23.y;                       // :119
+      xm = xm + km * s23.x;                               // :130
+      const double kb = s45.x * km;                       // :136
+#pragma unroll
+      for (int c = 0; c < 2 * NC; ++c) x[c] = __builtin_fma(-kb, y[c], x[c]);  // :141
+    }
+    ++k;
+  }
+  for (; barriers_left > 0; --barriers_left) __syncthreads();
+  if (bailed || g_ctl(&ctl[cBail]) != 0) return;  // nothing written back: the host re-runs Phase A
+  if (live) {
+    if (vec) store_row<PLg, NC, true>(a.Yp + (size_t)row * M, M, j, x);
+    else store_row<PLg, NC, false>(a.Yp + (size_t)row * M, M, j, x);
+    if (j == 0) a.ym[row] = xm;
+  }
+}
+
+template <int NC>
+hipError_t gram_launch(const PipeArgs& a, hipStream_t s) {
+  const long grid = (a.R + kRowsWG - 1) / kRowsWG;
+  const size_t lds = GramShape<NC>::lds_bytes(a.loc_mode != 0);
+  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_pipe_gram<NC>),
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  if (e != hipSuccess) return e;
+  hipLaunchKernelGGL((k_pipe_gram<NC>), dim3((unsigned)grid), dim3(kGT), lds, s, a);
+  return hipGetLastError();
+}
+
+}  // namespace
+
+bool pipeline_gram_supported(int M, long R, int loc_mode) {
+  if (!(M >= 2 && M <= 128 && R > 0 && (R + kRowsWG - 1) / kRowsWG <= kPipeMaxWGs)) return false;
+  const int nc = (M + 2 * PLg - 1) / (2 * PLg);
+  const int pad = 2 * PLg * nc, ts = pad + kTrajScalars;
+  const int sp = pad + ((2 - pad % 32) + 32) % 32;
+  const size_t ureg = (size_t)kRowsWG * (sp > 2 * kRowsWG + 8 ? sp : 2 * kRowsWG + 8);
+  const size_t bytes = ((size_t)kRingG * ts + kRowsWG * kRowsWG + ureg + 2 * kRowsWG + (loc_mode ? kRowsWG * kRowsWG : 0)) * 8 + 64;
+  return bytes <= 160 * 1024;
+}
+
+hipError_t launch_pipeline_gram(const PipeArgs& a, hipStream_t s) {
+  if (!pipeline_gram_supported(a.M, a.R, a.loc_mode) || a.P <= 0) return hipErrorInvalidValue;
+  switch ((a.M + 2 * PLg - 1) / (2 * PLg)) {
+    case 1: return gram_launch<1>(a, s);
+    case 2: return gram_launch<2>(a, s);
+    case 3: return gram_launch<3>(a, s);
+    case 4: return gram_launch<4>(a, s);
+    case 5: return gram_launch<5>(a, s);
+    case 6: return gram_launch<6>(a, s);
+    case 7: return gram_launch<7>(a, s);
+    case 8: return gram_launch<8>(a, s);
+    case 9: return gram_launch<9>(a, s);
+    case 10: return gram_launch<10>(a, s);
+    case 11: return gram_launch<11>(a, s);
+    case 12: return gram_launch<12>(a, s);
+    case 13: return gram_launch<13>(a, s);
+    case 14: return gram_launch<14>(a, s);
+    case 15: return gram_launch<15>(a, s);
+    case 16: return gram_launch<16>(a, s);
+    default: return hipErrorInvalidValue;
+  }
+}
+
+}  // namespace efa

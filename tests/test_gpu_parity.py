@@ -96,15 +96,18 @@ def test_phase_a_per_batch_kernels_and_pipeline_fallback(name):
     ctx = _ctx()
     ctx.set_option("path", 1)
     try:
-        for mode in ("pipeline", "batch", "expired"):
+        for mode in ("pipeline", "gram", "batch", "expired", "gram_expired"):
             N, xbm, Xbp = prior_arrays(g)
             ctx.set_option("pipeline", 0 if mode == "batch" else 1)
-            ctx.set_option("spin_limit", 1 if mode == "expired" else 4000000)
+            ctx.set_option("gram", 1 if mode.startswith("gram") else 0)
+            ctx.set_option("spin_limit", 1 if mode.endswith("expired") else 4000000)
             diag = ctx.ensrf_update_host(xbm, Xbp, N, g["ob_value"], g["ob_error"], g["ob_assim"],
                                          **golden_kwargs(g))
             kind = ctx.get_option("phase_a_kind")
             if mode == "pipeline":
                 assert kind == 1
+            if mode == "gram":
+                assert kind == 3
             if mode == "batch":
                 assert kind == 2
             assert_parity(xbm, g["xam"], "%s %s xam" % (name, mode))
@@ -113,6 +116,7 @@ def test_phase_a_per_batch_kernels_and_pipeline_fallback(name):
             assert np.array_equal(diag["assimilated"], g["assimilated"])
     finally:
         ctx.set_option("pipeline", 1)
+        ctx.set_option("gram", 0)
         ctx.set_option("spin_limit", 4000000)
         ctx.set_option("path", 0)
 
@@ -217,9 +221,11 @@ def _run_oracle(c):
 
 
 def _run_hip(c, path="auto", batch=32, pipeline=1):
+    """pipeline: 0 per-batch kernels, 1 persistent kernel (vector chain), 2 persistent kernel (Gram leader)"""
     ctx = _ctx()
     ctx.set_option("obs_batch", batch)
-    ctx.set_option("pipeline", pipeline)
+    ctx.set_option("pipeline", 1 if pipeline else 0)
+    ctx.set_option("gram", 1 if pipeline == 2 else 0)
     ctx.set_option("path", {"auto": 0, "sweep": 1, "transform": 2}[path])
     xbm, Xbp = orc.format_prior_state(c["X"], c["HX"])
     kw = dict(loc_mode=0)
@@ -230,6 +236,7 @@ def _run_hip(c, path="auto", batch=32, pipeline=1):
     ctx.set_option("path", 0)
     ctx.set_option("obs_batch", 64)
     ctx.set_option("pipeline", 1)
+    ctx.set_option("gram", 0)
     return xbm, Xbp, diag
 
 
@@ -246,7 +253,8 @@ SHAPES = [
 def test_seeded_shapes_vs_oracle(N, M, P, loc):
     c = _random_case(100 + N + M + P, N, M, P, loc, ncol=(N // 4 if loc and N % 4 == 0 and N >= 1024 else None))
     xam, Xap, diag = _run_oracle(c)
-    for path, pipe in ((("sweep", 1), ("auto", 1), ("sweep", 0)) if not loc else (("sweep", 1), ("sweep", 0))):
+    for path, pipe in ((("sweep", 1), ("auto", 1), ("sweep", 0), ("sweep", 2), ("auto", 2)) if not loc
+                       else (("sweep", 1), ("sweep", 0), ("sweep", 2))):
         h_xam, h_Xap, h_diag = _run_hip(c, path=path, pipeline=pipe)
         assert_parity(h_xam, xam, "xam %s" % path)
         assert_parity(h_Xap, Xap, "Xap %s" % path)
