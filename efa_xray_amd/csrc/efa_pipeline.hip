@@ -330,10 +330,17 @@ __global__ __launch_bounds__(kPT) void k_pipe(const PipeArgs a) {
     wq1 = (P > 1) ? a.tw[(size_t)1 * R + row] : 1.0;
   }
 
+  // cycle stamps for tools/pipe_stamps.py: diagnostic builds only (make STAMPS=1), see efa_pipeline_gram.hip
+#ifdef EFA_PIPE_STAMPS
 #define EFA_STAMP(i)                                                                     \
   do {                                                                                   \
     if (a.dbg != nullptr && pub && j == 0) a.dbg[(size_t)k * 8 + (i)] = __builtin_amdgcn_s_memtime(); \
   } while (0)
+#else
+#define EFA_STAMP(i) \
+  do {                \
+  } while (0)
+#endif
   for (long k = 0; k < P && !bailed; ++k) {
     const double* slot = ring + (size_t)(k % kRing) * TS;
     const long kn = k + 1, k2 = k + 2;

@@ -86,7 +86,7 @@ struct GramShape {
   static constexpr int SP = PAD + ((2 - PAD % 32) + 32) % 32;  // tile row stride == 2 (mod 32): conflict-free operand reads
   static constexpr int UREG = (kRowsWG * SP > kRowsWG * (2 * kRowsWG + 8)) ? kRowsWG * SP : kRowsWG * (2 * kRowsWG + 8);
   static size_t lds_bytes(bool gc) {
-    return ((size_t)kRingG * TS + kRowsWG * kRowsWG + UREG + 2 * kRowsWG + (gc ? kRowsWG * kRowsWG : 0)) * sizeof(double) +
+    return ((size_t)kRingG * TS + kRowsWG * kRowsWG + UREG + 5 * kRowsWG + (gc ? kRowsWG * kRowsWG : 0)) * sizeof(double) +
            16 * sizeof(int);
   }
 };
@@ -96,13 +96,14 @@ __global__ __launch_bounds__(kGT) void k_pipe_gram(const PipeArgs a) {
   using Sh = GramShape<NC>;
   constexpr int PAD = Sh::PAD, TS = Sh::TS, SP = Sh::SP, UREG = Sh::UREG;
   constexpr int EPL = (TS + 63) / 64;
-  constexpr int NMR = (PAD + 63) / 64;  // registers per row in the block's lane = member layout
+  constexpr int NJ = (PAD + 15) / 16;  // accumulator tiles per wave in the block's matrix-core layout
   extern __shared__ __align__(16) double lds[];
   double* ring = lds;                          // [kRingG][TS]   ye rows (+ scalars in follower mode)
   double* G_s = ring + kRingG * TS;            // [64][64]       Gram matrix of the block
   double* U = G_s + kRowsWG * kRowsWG;         // union: Yt[64][SP]  then  {g, kb}[64][64], sc[64][8]
   double* pm = U + UREG;                       // [2][64]        parked row means / obs-space means
-  double* tw_s = pm + 2 * kRowsWG;             // [64][64]       taper corner (GC only)
+  double* pv = pm + 2 * kRowsWG;               // [3][64]        ob value / error / sqrt(error) of the block
+  double* tw_s = pv + 3 * kRowsWG;             // [64][64]       taper corner (GC only)
   int* ctl = reinterpret_cast<int*>(tw_s + (a.loc_mode != 0 ? kRowsWG * kRowsWG : 0));  // [16]
   double* Yt = U;
   // per-step records of the pivot wave.  kmat of step kk goes into row kk of G_s: that row is dead by
@@ -125,10 +126,22 @@ __global__ __launch_bounds__(kGT) void k_pipe_gram(const PipeArgs a) {
   if (tid < 16) ctl[tid] = (tid >= cProg) ? -1 : (tid == cFwd ? (int)(own0 - 1) : 0);
   __syncthreads();
 
+  // Cycle stamps for tools/gram_stamps*.py exist only in diagnostic builds (make STAMPS=1): an s_memtime
+  // anywhere in a loop makes the compiler wait for ALL outstanding LDS traffic (lgkmcnt(0)) wherever it
+  // waits at all, because scalar-memory results may return out of order with LDS results.
+#ifdef EFA_PIPE_STAMPS
+#define EFA_EXP(bit) ((a.debug & (bit)) != 0)  /* timing experiments of tools/gram_exp*.py: results are wrong */
 #define EFA_GSTAMP(cond, kidx, slot)                                                                          \
   do {                                                                                                          \
-    if (a.dbg != nullptr && (cond)) a.dbg[(size_t)(kidx) * 8 + (slot)] = __builtin_amdgcn_s_memtime();       \
+    if (a.dbg != nullptr && (!(a.debug & 128) || (slot) == 0 || (slot) == 7) && (cond))                         \
+      a.dbg[(size_t)(kidx) * 8 + (slot)] = __builtin_amdgcn_s_memtime();                                        \
   } while (0)
+#else
+#define EFA_EXP(bit) false
+#define EFA_GSTAMP(cond, kidx, slot) \
+  do {                                \
+  } while (0)
+#endif
   long budget = a.spin_limit;
   int polls = 0;
   auto give_up = [&]() {
@@ -147,7 +160,8 @@ __global__ __launch_bounds__(kGT) void k_pipe_gram(const PipeArgs a) {
           return false;
         }
       }
-      if (doze) __builtin_amdgcn_s_sleep(1);
+      if (EFA_EXP(512)) __builtin_amdgcn_s_sleep(6);
+      else if (doze) __builtin_amdgcn_s_sleep(1);
     }
     return true;
   };
@@ -164,7 +178,8 @@ __global__ __launch_bounds__(kGT) void k_pipe_gram(const PipeArgs a) {
           return false;
         }
       }
-      if (doze) __builtin_amdgcn_s_sleep(1);
+      if (EFA_EXP(512)) __builtin_amdgcn_s_sleep(6);
+      else if (doze) __builtin_amdgcn_s_sleep(1);
     }
   };
 
@@ -300,41 +315,84 @@ __global__ __launch_bounds__(kGT) void k_pipe_gram(const PipeArgs a) {
     __syncthreads();  // B2
     if (wave == kVW) {
       // ---------------- pivot wave: lane j <-> row j of the workgroup ----------------
+      // The loop below is the serial chain of the whole filter, and one wave issues in order: every
+      // instruction in it costs issue slots, so per-step work is kept to the recurrence itself.
+      // Per-ob constants come from LDS with uniform addresses, diagnostics are reconstructed from the
+      // step records after the loop, and the gain factors are arranged for a short dependent chain:
+      //   kdenom -> q0 = rsq(kdenom) -> { Newton step of q  ||  beta0 = 1/(1 + sqrt(err) q0) } -> beta
+      // with beta = beta0 - beta0^2 sqrt(err) q0 d for q = q0 (1 + d)  (d ~ 1e-8: the d^2 term is < 1 ulp).
       const long obj = own0 + lane;
       const bool is_ob = lane < nb;
       double mu = pm[lane], xmv = pm[kRowsWG + lane];
-      const double val = is_ob ? a.ob_value[obj] : 0.0;
       const double err = is_ob ? a.ob_error[obj] : 1.0;
-      const double sq = sqrt(err);
-      const int asmf = is_ob ? (a.ob_assim[obj] != 0 ? 1 : 0) : 0;
-      const double d0 = is_ob ? G_s[lane * kRowsWG + lane] : 1.0;
-      double o_pm = 0.0, o_pv = 0.0, o_in = 0.0, o_rd = 0.0, o_be = 0.0, o_qm = 0.0, o_qv = 0.0;
-      bool o_done = false, bailed = false;
+      const bool my_asm = is_ob && a.ob_assim[obj] != 0;
+      pv[lane] = is_ob ? a.ob_value[obj] : 0.0;
+      pv[kRowsWG + lane] = err;
+      pv[2 * kRowsWG + lane] = sqrt(err);
+      const u64 asm_mask = __ballot(my_asm);
+      // cancellation guard: an assimilated pivot whose G_kk fell below 1e-3 of its value at block start
+      const double thr = my_asm ? 1e-3 * G_s[lane * kRowsWG + lane] : -1.0;
+      bool bailed = false;
       double g = G_s[lane];             // row 0
       double g1 = G_s[kRowsWG + lane];  // row 1
+      // per-ob constants (and the taper row) are fetched one step ahead: an LDS round trip at the top of a
+      // step would sit on the chain
+      double valn = pv[0], errn = pv[kRowsWG], sqn = pv[2 * kRowsWG];
+      const bool gc = a.loc_mode != 0;
+      const double* twp = gc ? tw_s + lane : pv + lane;  // always a valid address: the load is unconditional
+      double twn = twp[0];
       __builtin_amdgcn_s_setprio(3);
+#ifdef EFA_PIPE_STAMPS
+      const bool seg = (a.debug & 256) != 0 && a.dbg != nullptr;
+#else
+      constexpr bool seg = false;
+#endif
+      u64 segsum[4] = {0, 0, 0, 0}, tprev = 0;
       for (int kk = 0; kk < nb; ++kk) {
+        u64 T0 = 0, T1 = 0, T2 = 0, T3 = 0;
+        if (seg) T0 = __builtin_amdgcn_s_memtime();
         EFA_GSTAMP(lane == 0, own0 + kk, 0);
-        const int f_early = g_ctl_lane(&ctl[cHProg + (kk & 1)]);  // flag first, then the row (LDS keeps the order)
-        double r2 = G_s[((kk + 2 < kRowsWG) ? kk + 2 : 0) * kRowsWG + lane];
-        const double Gkk = rl(g, kk), muk = rl(mu, kk), xmk = rl(xmv, kk);
-        const double valk = rl(val, kk), errk = rl(err, kk), sqk = rl(sq, kk);
-        const bool act = __builtin_amdgcn_readlane(asmf, kk) != 0;
-        const double var = __builtin_fma(Gkk, invM, -(muk * muk));   // np.var, ddof = 0 (:69)
-        if (act && !(Gkk > 1e-3 * rl(d0, kk))) {  // the downdate may have cancelled: leave it to efa_pipeline.hip
+        const double valk = valn, errk = errn, sqk = sqn, twk = twn;
+        {
+          const int kn = (kk + 1 < kRowsWG) ? kk + 1 : kk;
+          valn = pv[kn];
+          errn = pv[kRowsWG + kn];
+          sqn = pv[2 * kRowsWG + kn];
+          twn = twp[gc ? kn * kRowsWG : 0];
+        }
+        const bool act = ((asm_mask >> kk) & 1) != 0;
+        if (((__ballot(!(g > thr)) >> kk) & 1) != 0 && !EFA_EXP(0x70)) {  // the downdate may have cancelled: leave it to efa_pipeline.hip
           if (lane == 0) give_up();
           bailed = true;
           break;
         }
-        const double innov = valk - xmk;                              // :85
-        const double kdenom = var + errk;                             // :91
-        const double q = g_rsq(kdenom);
-        const double rden = q * q;
-        const double beta = g_rcp(1.0 + sqk * q);                     // :135
+        const double Gkk = rl(g, kk), muk = rl(mu, kk), xmk = rl(xmv, kk);
+        const double mu2 = muk * muk;
+        const double kdenom = __builtin_fma(Gkk, invM, errk - mu2);   // var + err  (:69, :91)
+        const double q0 = __builtin_amdgcn_rsq(kdenom);
+        const double e = __builtin_fma(-kdenom * q0, q0, 1.0);
+        const double d = e * __builtin_fma(0.375, e, 0.5);            // q = q0 (1 + d)
+        const double q = __builtin_fma(q0, d, q0);
+        const double rden = q * q;                                    // 1 / kdenom
+        const double sq0 = sqk * q0;
+        const double b0 = 1.0 + sq0;
+        const double r0 = __builtin_amdgcn_rcp(b0);
+        const double eb = __builtin_fma(-b0, r0, 1.0);
+        const double beta0 = __builtin_fma(r0, __builtin_fma(eb, eb, eb), r0);
+        const double beta = __builtin_fma(-((beta0 * beta0) * sq0), d, beta0);  // 1 / (1 + sqrt(err / kdenom))  (:135)
         double kc = g * rM1;                                          // :95
-        if (a.loc_mode != 0) kc = tw_s[kk * kRowsWG + lane] * kc;     // :115
+        if (gc) kc = twk * kc;                                        // :115
         const double km = act ? kc * rden : 0.0;                      // :119
         const double kb = beta * km;                                  // :136
+        const double innov = valk - xmk;                              // :85
+        // row kk+2 from its helper, read speculatively here (the helper had the whole gain chain above to
+        // hand it over; the round trip overlaps the publication below): flag first, then the row
+        const int f_early = g_ctl_lane(&ctl[cHProg + (kk & 1)]);
+        double r2 = G_s[((kk + 2 < kRowsWG) ? kk + 2 : 0) * kRowsWG + lane];
+        if (seg) {
+          asm volatile("" ::"v"(kb));
+          T1 = __builtin_amdgcn_s_memtime();
+        }
         s_km[kk * kRowsWG + lane] = km;
         s_gk[kk * kRowsWG + lane] = make_double2(g, kb);
         if (lane == 0) {
@@ -342,31 +400,19 @@ __global__ __launch_bounds__(kGT) void k_pipe_gram(const PipeArgs a) {
           sc[0] = make_double2(xmk, muk);
           sc[1] = make_double2(innov, rden);
           sc[2] = make_double2(beta, act ? 1.0 : 0.0);
-          sc[3] = make_double2(var, Gkk);
+          sc[3] = make_double2(__builtin_fma(Gkk, invM, -mu2), Gkk);  // np.var, ddof = 0 (:69)
           g_ctl_set(&ctl[cSReady], kk + 1);
         }
         EFA_GSTAMP(lane == 0, own0 + kk, 1);
-        if (lane == kk) {
-          o_pm = xmk;   // :66
-          o_pv = var;   // :70
-          o_in = innov;
-          o_rd = rden;
-          o_be = beta;
-        }
+        if (seg) T2 = __builtin_amdgcn_s_memtime();
         xmv = xmv + km * innov;                                       // :130
         mu = __builtin_fma(-kb, muk, mu);
-        if (lane == kk && act) {
-          const double f = 1.0 - kb;  // the ob's own row is scaled by (1 - kb)  (:144-149)
-          o_qv = (f * f) * var;
-          o_qm = xmv;
-          o_done = true;
-        }
         if (kk + 1 < nb) {
           // g1 = row kk+1 through step kk-1; row kk+2 through step kk-1 comes from its helper (handed
-          // over through G_s during the helper's step kk-1, read speculatively at the top of this step)
-          const double t = g - kb * Gkk;
+          // over through G_s during the helper's step kk-1, read speculatively before the publication above)
+          const double t = __builtin_fma(-kb, Gkk, g);
           const double gi = rl(g, kk + 1), ai = rl(kb, kk + 1);
-          const double gnew = g1 - (kb * gi + ai * t);
+          const double gnew = __builtin_fma(-ai, t, __builtin_fma(-kb, gi, g1));
           if (kk + 2 < nb) {
             if (kk >= 1 && __builtin_amdgcn_readfirstlane(f_early) < kk + 2) {
               const int* flag = &ctl[cHProg + (kk & 1)];
@@ -387,27 +433,53 @@ __global__ __launch_bounds__(kGT) void k_pipe_gram(const PipeArgs a) {
               if (bailed) break;
             }
             const double gi2 = rl(g, kk + 2), ai2 = rl(kb, kk + 2);
-            g1 = r2 - (kb * gi2 + ai2 * t);
+            g1 = __builtin_fma(-ai2, t, __builtin_fma(-kb, gi2, r2));
           }
           g = gnew;
           EFA_GSTAMP(lane == 0, own0 + kk, 2);
         }
+        if (seg) {
+          asm volatile("" ::"v"(g), "v"(g1));
+          T3 = __builtin_amdgcn_s_memtime();
+          if (kk >= 4 && kk < 60) {
+            segsum[0] += T1 - T0;
+            segsum[1] += T2 - T1;
+            segsum[2] += T3 - T2;
+            segsum[3] += T0 - tprev;
+          }
+          tprev = T3;
+        }
+      }
+      if (seg && lane == 0 && nb == kRowsWG) {
+        for (int i = 0; i < 4; ++i) a.dbg[(size_t)(own0 + i) * 8 + 5] = segsum[i];
       }
       pm[kRowsWG + lane] = xmv;  // obs-space means of all 64 rows after the block, back to the vector waves
       __builtin_amdgcn_s_setprio(0);
+      // diagnostics of this block's obs from the step records (lane = ob)
+      double o_pm = 0.0, o_pv = 0.0, o_in = 0.0, o_rd = 0.0, o_be = 0.0, o_km = 0.0;
+      if (is_ob && !bailed) {
+        const double* sc = s_sc + (size_t)lane * 8;
+        o_pm = sc[0];   // :66
+        o_in = sc[2];
+        o_rd = sc[3];
+        o_be = sc[4];
+        o_pv = sc[6];   // :70
+        o_km = s_km[lane * kRowsWG + lane];
+      }
       __syncthreads();  // B3
       if (!bailed && g_ctl(&ctl[cBail]) == 0 && is_ob) {
         a.prior_mean[obj] = o_pm;
         a.prior_var[obj] = o_pv;
         double* ck = a.coef + (size_t)obj * kCoefStride;
-        ck[0] = asmf ? o_in : 0.0;
-        ck[1] = asmf ? o_rd : 0.0;
-        ck[2] = asmf ? o_be : 0.0;
-        ck[3] = asmf ? 1.0 : 0.0;
-        a.assimilated[obj] = o_done ? 1 : 0;  // :74-76, :149
-        if (o_done) {
-          a.post_mean[obj] = o_qm;
-          a.post_var[obj] = o_qv;
+        ck[0] = my_asm ? o_in : 0.0;
+        ck[1] = my_asm ? o_rd : 0.0;
+        ck[2] = my_asm ? o_be : 0.0;
+        ck[3] = my_asm ? 1.0 : 0.0;
+        a.assimilated[obj] = my_asm ? 1 : 0;  // :74-76, :149
+        if (my_asm) {
+          const double f = 1.0 - o_be * o_km;  // the ob's own row is scaled by (1 - kb)  (:144-149)
+          a.post_mean[obj] = o_pm + o_km * o_in;  // :130
+          a.post_var[obj] = (f * f) * o_pv;
         }
       }
       return;
@@ -455,6 +527,13 @@ __global__ __launch_bounds__(kGT) void k_pipe_gram(const PipeArgs a) {
       EFA_GSTAMP(lane == 0 && h == ((kk + 1) & 1) && !(a.debug & 8), own0 + kk, 5);
       EFA_GSTAMP(lane == 0 && h == 0 && (a.debug & 8), own0 + kk, 4);
       // rows behind the pivot may be updated too (their registers are dead)
+      if (EFA_EXP(16)) {  // timing experiment: hand-over only
+        if (((kk + 3) & 1) == h) {
+          G_s[(kk + 3) * kRowsWG + lane] = gr[0];
+          if (lane == 0) g_ctl_set(&ctl[cHProg + h], kk + 3);
+        }
+        continue;
+      }
       if (kk + 3 < 32) downdate(rec, kb, t, kk, std::integral_constant<int, 0>());
       EFA_GSTAMP(lane == 0 && h == 0 && (a.debug & 8), own0 + kk, 5);
       downdate(rec, kb, t, kk, std::integral_constant<int, 1>());
@@ -514,95 +593,115 @@ __global__ __launch_bounds__(kGT) void k_pipe_gram(const PipeArgs a) {
       }
       __syncthreads();  // B1: tile and parked means complete
       form_gram();
-      // For the block the rows change layout: "lane = member".  Wave w re-reads the 16 rows it has
-      // just parked (rows 4 q + w) with lane m holding members m and 64 + m.  An axpy then needs ye as
-      // two per-lane values instead of the 13 quad-replicated ds_read_b128 of the follower layout:
-      // the LDS pipe, which all eight waves share, is what bounds the block otherwise.
-      // Slot q of wave w holds row 4 ((q + rot) & 15) + w: the slots are rotated each time the wave has
-      // published a row, so that the next row this wave publishes is always in slot 0 (static registers).
-      double xr[16][NMR];
+      // For the block the rows change layout.  Wave w re-reads the 16 rows it has just parked (rows
+      // 4 rho + w, rho = 0..15) as NJ accumulator tiles of v_mfma_f64_16x16x4_f64: register v of tile J in
+      // lane l is member 16 J + (l & 15) of tile row rho = 4 v + (l >> 4).  With the gains kb known from
+      // the pivot wave, the rows are then updated
+      //   - by ONE matrix-core instruction per tile for every four steps (rank-4 update, A = -kb of the
+      //     four steps, B = their four ye), off the chain, and
+      //   - step by step only inside a window of the next eight rows to be published (a per-lane
+      //     coefficient, zero outside the window; those (row, step) pairs are masked out of the rank-4
+      //     update), so that the row that becomes ye of the next ob is always current.
+      // The quad layout's 13 replicated ds_read_b128 per wave and step (the LDS pipe is shared by all
+      // eight waves) and its 26 FMAs per wave and step shrink to 7 ds_read_b64 and <= 14 FMAs.
+      v4f64 xt[NJ];
+      const int lr = lane >> 4, lc = lane & 15;
 #pragma unroll
-      for (int q = 0; q < 16; ++q)
+      for (int J = 0; J < NJ; ++J)
 #pragma unroll
-        for (int e = 0; e < NMR; ++e) xr[q][e] = Yt[(size_t)(4 * q + wave) * SP + 64 * e + lane];
+        for (int v = 0; v < 4; ++v) xt[J][v] = Yt[(size_t)(16 * v + 4 * lr + wave) * SP + 16 * J + lc];
       __syncthreads();  // B2: G complete; the tile region now belongs to the pivot wave's records
       barriers_left = 1;
-      int rot = 0;
-      auto rotate = [&]() {
-        double t0[NMR];
-#pragma unroll
-        for (int e = 0; e < NMR; ++e) t0[e] = xr[0][e];
-#pragma unroll
-        for (int q = 0; q < 15; ++q)
-#pragma unroll
-          for (int e = 0; e < NMR; ++e) xr[q][e] = xr[q + 1][e];
-#pragma unroll
-        for (int e = 0; e < NMR; ++e) xr[15][e] = t0[e];
-        rot = (rot + 1) & 15;
+      auto publish_row = [&](int r) {  // block row r (held by this wave: (r & 3) == wave) IS ye of ob own0 + r
+        double* slot = ring + (size_t)((own0 + r) % kRingG) * TS;
+        if (lr == ((r >> 2) & 3)) {
+          switch (r >> 4) {
+#define EFA_PUB_CASE(V)                                                      \
+  case V:                                                                    \
+    _Pragma("unroll") for (int J = 0; J < NJ; ++J)                           \
+      if (16 * J + lc < PAD) slot[16 * J + lc] = xt[J][V];                   \
+    break;
+            EFA_PUB_CASE(0)
+            EFA_PUB_CASE(1)
+            EFA_PUB_CASE(2)
+            EFA_PUB_CASE(3)
+#undef EFA_PUB_CASE
+          }
+        }
+        if (lane == 0) g_ctl_set(&ctl[cReady], (int)(own0 + r + 1));
       };
-      auto publish_slot0 = [&](long kn) {  // slot 0 IS ye of ob kn
-        double* slot = ring + (size_t)(kn % kRingG) * TS;
-#pragma unroll
-        for (int e = 0; e < NMR; ++e)
-          if (64 * e + lane < PAD) slot[64 * e + lane] = xr[0][e];
-        if (lane == 0) g_ctl_set(&ctl[cReady], (int)(kn + 1));
-      };
-      if (wave == 0) {
-        publish_slot0(own0);
-        rotate();
-      }
-      for (int kk = 0; kk < nb; ++kk) {
-        const long kg = own0 + kk;
-        const int nu = kk + 1;                                          // the row that is ye of the next ob
-        const bool mine = ((nu & (kVW - 1)) == wave) && nu < nb;        // ... is held by this wave (in slot 0)
-        if (!wait2_gt(&ctl[cReady], (int)kg, &ctl[cSReady], kk, !mine)) {
+      if (wave == 0) publish_row(0);
+      for (int st = 0; st < nb; ++st) {
+        const long kg = own0 + st;
+        const int hi = 4 * ((st + 1) >> 2) + 7;                         // window: rows st < r <= hi
+        const int nu = st + 1;                                          // the row that is ye of the next ob
+        const bool mine = ((nu & (kVW - 1)) == wave) && nu < nb;        // ... is held by this wave
+        const bool batch = ((st & 3) == 2) || st == nb - 1;             // a group of four steps is complete
+        const bool inwin_any = (60 + wave > st) && (wave <= hi);        // some row of this wave is in the window
+        if (!inwin_any && !batch) continue;
+        if (!wait2_gt(&ctl[cReady], (int)kg, &ctl[cSReady], st, !mine)) {
           bailed = true;
           break;
         }
         EFA_GSTAMP(mine && lane == 0 && !(a.debug & 8), kg, 3);
-        const double* slot = ring + (size_t)(kg % kRingG) * TS;
-        double y[NMR];
+        if (inwin_any && EFA_EXP(64)) {
+          if (mine) publish_row(nu);
+        } else if (inwin_any) {
+          const double* slot = ring + (size_t)(kg % kRingG) * TS;
+          double y[NJ];
 #pragma unroll
-        for (int e = 0; e < NMR; ++e) y[e] = slot[64 * e + lane];
-        const double kmv = s_km[kk * kRowsWG + lane];                   // lane = row of the workgroup
-        const double beta = s_sc[kk * 8 + 4];
-        if (lane == 0) g_ctl_set(&ctl[cProg + wave], (int)kg);
-        const double kbv = beta * kmv;                                  // :136
-        {
-          const double kb = rl(kbv, 4 * rot + wave);
+          for (int J = 0; J < NJ; ++J) y[J] = slot[16 * J + lc];
 #pragma unroll
-          for (int e = 0; e < NMR; ++e) xr[0][e] = __builtin_fma(-kb, y[e], xr[0][e]);  // :141
-        }
-        if (mine) {  // the chain: publish the next ye before the other fifteen rows are touched
-          if ((nu & 3) == 0) {  // recycling guard, amortised over four records
-            while (min_prog() < (int)(kg + 1 + 3 - kRingG)) {
-              if (g_ctl(&ctl[cBail]) != 0 || --budget <= 0) {
-                bailed = true;
-                break;
-              }
+          for (int v = 0; v < 4; ++v) {
+            if (16 * v + 12 + wave > st && 16 * v + wave <= hi) {       // uniform: tile rows 4v..4v+3 touch the window
+              const int row = 16 * v + 4 * lr + wave;
+              double kb = s_gk[st * kRowsWG + row].y;                   // :136
+              if (!(row > st && row <= hi)) kb = 0.0;
+#pragma unroll
+              for (int J = 0; J < NJ; ++J) xt[J][v] = __builtin_fma(-kb, y[J], xt[J][v]);  // :141
             }
-            if (bailed) break;
           }
-          publish_slot0(kg + 1);
-          EFA_GSTAMP(lane == 0 && !(a.debug & 8), kg, 4);
+          if (mine) {  // the chain: publish the next ye
+            if ((nu & 3) == 0) {  // recycling guard, amortised over four records
+              while (min_prog() < (int)(kg + 1 + 3 - kRingG)) {
+                if (g_ctl(&ctl[cBail]) != 0 || --budget <= 0) {
+                  bailed = true;
+                  break;
+                }
+              }
+              if (bailed) break;
+            }
+            publish_row(nu);
+            EFA_GSTAMP(lane == 0 && !(a.debug & 8), kg, 4);
+          }
         }
+        if (batch && EFA_EXP(32)) {
+          if (lane == 0) g_ctl_set(&ctl[cProg + wave], (int)kg);
+        } else if (batch) {
+          // rank-4 update with the steps 4 tp - 1 .. 4 tp + 2 (those that exist), minus what the window did
+          const int tp = (st + 1) >> 2;
+          const int sa = 4 * tp - 1 + lr;                               // this lane's k slice
+          const bool valid = sa >= 0 && sa <= st;
+          const int sc = valid ? sa : st;
+          const int row = 4 * lc + wave;                                // A: tile row rho = l & 15
+          double av = s_gk[sc * kRowsWG + row].y;
+          if (!valid || (row > sa && row <= 4 * tp + 7)) av = 0.0;
+          av = -av;
+          const double* bs = ring + (size_t)((own0 + sc) % kRingG) * TS;
 #pragma unroll
-        for (int q = 1; q < 16; ++q) {
-          const double kb = rl(kbv, 4 * ((q + rot) & 15) + wave);
-#pragma unroll
-          for (int e = 0; e < NMR; ++e) xr[q][e] = __builtin_fma(-kb, y[e], xr[q][e]);  // :141
+          for (int J = 0; J < NJ; ++J) xt[J] = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bs[16 * J + lc], xt[J], 0, 0, 0);
+          if (lane == 0) g_ctl_set(&ctl[cProg + wave], (int)kg);       // ring slots up to kg consumed
         }
-        if (mine) rotate();
       }
       __syncthreads();  // B3: every wave is done with the pivot's records; the tile region is free again
       barriers_left = 0;
       if (bailed) break;
       // back to the follower layout through the tile (each wave reads only rows it wrote itself)
 #pragma unroll
-      for (int q = 0; q < 16; ++q)
+      for (int J = 0; J < NJ; ++J)
 #pragma unroll
-        for (int e = 0; e < NMR; ++e)
-          if (64 * e + lane < PAD) Yt[(size_t)(4 * ((q + rot) & 15) + wave) * SP + 64 * e + lane] = xr[q][e];
+        for (int v = 0; v < 4; ++v)
+          if (16 * J + lc < PAD) Yt[(size_t)(16 * v + 4 * lr + wave) * SP + 16 * J + lc] = xt[J][v];
 #pragma unroll
       for (int c = 0; c < NC; ++c) {
         const double2 v = *reinterpret_cast<const double2*>(Yt + (size_t)i_loc * SP + 2 * PLg * c + 2 * j);
@@ -628,6 +727,10 @@ __global__ __launch_bounds__(kGT) void k_pipe_gram(const PipeArgs a) {
     const double w = wq0;
     wq0 = wq1;
     if (use_tw) wq1 = a.tw[(size_t)((k + 2 < P) ? k + 2 : P - 1) * R + row];
+    if (EFA_EXP(1024) && own0 >= 128) {  // TIMING EXPERIMENT: followers far from the leader skip their work
+      ++k;
+      continue;
+    }
     if (__builtin_amdgcn_readfirstlane((int)(s45.y != 0.0)) != 0) {
       const double dot = group_dot<PLg, NC>(x, y);
       double kc = dot * rM1;                              // :95
@@ -668,7 +771,7 @@ bool pipeline_gram_supported(int M, long R, int loc_mode) {
   const int pad = 2 * PLg * nc, ts = pad + kTrajScalars;
   const int sp = pad + ((2 - pad % 32) + 32) % 32;
   const size_t ureg = (size_t)kRowsWG * (sp > 2 * kRowsWG + 8 ? sp : 2 * kRowsWG + 8);
-  const size_t bytes = ((size_t)kRingG * ts + kRowsWG * kRowsWG + ureg + 2 * kRowsWG + (loc_mode ? kRowsWG * kRowsWG : 0)) * 8 + 64;
+  const size_t bytes = ((size_t)kRingG * ts + kRowsWG * kRowsWG + ureg + 5 * kRowsWG + (loc_mode ? kRowsWG * kRowsWG : 0)) * 8 + 64;
   return bytes <= 160 * 1024;
 }
 

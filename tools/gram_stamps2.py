@@ -1,4 +1,6 @@
 """Diagnostic: helper-wave detail stamps of the Gram-space leader (pipe_debug 4|8)."""
+# Needs the diagnostic build of the library:  make -C efa_xray_amd/csrc clean all STAMPS=1
+# (cycle stamps and timing switches are compiled out of the normal build).
 import sys, os, ctypes
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
