@@ -119,89 +119,93 @@ __global__ __launch_bounds__(kPT) void k_pipe(const PipeArgs a) {
   // loader wave
   // =====================================================================================
   if (wave == kCW) {
-    long next = 0;
+    // Three phases, each its own loop: follow the records before the own block, forward the own block,
+    // follow the rest.  (As ONE loop the compiler merged the poll path's pending-load state into the
+    // forward path and waited vmcnt(0) per forwarded record -- i.e. for the previous record's
+    // write-through store to complete, ~1400 cycles per ob, which bounded the whole kernel.)
     long spins_left = a.spin_limit;
     bool failed = false;
-    while (next < P && !failed) {
-      if (next >= own0 && next < own1) {
-        // leader phase: the owners publish into the LDS ring only; this wave forwards each
-        // finished record to global memory (agent-scope granules) for the other workgroups
-        for (long f = own0; f < own1 && !failed; ++f) {
-          while (ctl_load(&ctl[kReadyYe]) <= (int)f) {
-            if (--spins_left <= 0 || ctl_load(&ctl[kBail]) != 0) {
-              failed = true;
-              break;
-            }
-            __builtin_amdgcn_s_sleep(1);
-          }
-          if (failed) break;
-          const double* slot = ring + (size_t)(f % kRing) * TS;
-          u64* rec = a.traj + (size_t)f * TS;
-          if (!(a.debug & 1)) {
+    auto follow = [&](long next, const long limit) {
+      while (next < limit && !failed) {
+        const int nrec = (int)((limit - next < kPoll) ? (limit - next) : kPoll);
+        u64 v[kPoll][EPL];
 #pragma unroll
-            for (int e = 0; e < EPL; ++e) {
-              const int idx = lane + 64 * e;
-              if (idx < TS) traj_store(rec + idx, slot[idx]);
-            }
-          }
-          if (lane == 0) ctl_store(&ctl[kFwd], (int)f);
-        }
-        next = own1;
-        continue;
-      }
-      const long limit = (next < own0) ? ((own0 < P) ? own0 : P) : P;
-      const int nrec = (int)((limit - next < kPoll) ? (limit - next) : kPoll);
-      u64 v[kPoll][EPL];
-#pragma unroll
-      for (int d = 0; d < kPoll; ++d) {
-        const long kk = next + ((d < nrec) ? d : nrec - 1);
-        const u64* rec = a.traj + (size_t)kk * TS;
-#pragma unroll
-        for (int e = 0; e < EPL; ++e) {
-          const int idx = lane + 64 * e;
-          v[d][e] = traj_load(rec + (idx < TS ? idx : TS - 1));
-        }
-      }
-      int cnt = 0;
-#pragma unroll
-      for (int d = 0; d < kPoll; ++d) {
-        bool ok = true;
-#pragma unroll
-        for (int e = 0; e < EPL; ++e) ok = ok && (v[d][e] != kTrajSentinel);
-        if (cnt == d && d < nrec && __all(ok)) cnt = d + 1;
-      }
-      if (cnt == 0) {
-        if (--spins_left <= 0 || __hip_atomic_load(a.status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0)
-          failed = true;
-        __builtin_amdgcn_s_sleep(2);
-        continue;
-      }
-      // ring slots may be recycled only when every compute wave consumed their old record
-      const long need = next + cnt - 1 - kRing;  // all prog[w] must be >= need
-      if (need >= 0) {
-        for (;;) {
-          const int mn = __builtin_amdgcn_readfirstlane(group8_min(ctl_load_lane(&ctl[kProg + (lane & (kCW - 1))])));
-          if (mn >= (int)need) break;
-          if (--spins_left <= 0) {
-            failed = true;
-            break;
-          }
-        }
-        if (failed) break;
-      }
-#pragma unroll
-      for (int d = 0; d < kPoll; ++d) {
-        if (d < cnt) {
-          double* slot = ring + (size_t)((next + d) % kRing) * TS;
+        for (int d = 0; d < kPoll; ++d) {
+          const long kk = next + ((d < nrec) ? d : nrec - 1);
+          const u64* rec = a.traj + (size_t)kk * TS;
 #pragma unroll
           for (int e = 0; e < EPL; ++e) {
             const int idx = lane + 64 * e;
-            if (idx < TS) slot[idx] = __longlong_as_double((long long)v[d][e]);
+            v[d][e] = traj_load(rec + (idx < TS ? idx : TS - 1));
           }
         }
+        int cnt = 0;
+#pragma unroll
+        for (int d = 0; d < kPoll; ++d) {
+          bool ok = true;
+#pragma unroll
+          for (int e = 0; e < EPL; ++e) ok = ok && (v[d][e] != kTrajSentinel);
+          if (cnt == d && d < nrec && __all(ok)) cnt = d + 1;
+        }
+        if (cnt == 0) {
+          if (--spins_left <= 0 || __hip_atomic_load(a.status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0)
+            failed = true;
+          __builtin_amdgcn_s_sleep(2);
+          continue;
+        }
+        // ring slots may be recycled only when every compute wave consumed their old record
+        const long need = next + cnt - 1 - kRing;  // all prog[w] must be >= need
+        if (need >= 0) {
+          for (;;) {
+            const int mn = __builtin_amdgcn_readfirstlane(group8_min(ctl_load_lane(&ctl[kProg + (lane & (kCW - 1))])));
+            if (mn >= (int)need) break;
+            if (--spins_left <= 0) {
+              failed = true;
+              break;
+            }
+          }
+          if (failed) break;
+        }
+#pragma unroll
+        for (int d = 0; d < kPoll; ++d) {
+          if (d < cnt) {
+            double* slot = ring + (size_t)((next + d) % kRing) * TS;
+#pragma unroll
+            for (int e = 0; e < EPL; ++e) {
+              const int idx = lane + 64 * e;
+              if (idx < TS) slot[idx] = __longlong_as_double((long long)v[d][e]);
+            }
+          }
+        }
+        next += cnt;
+        if (lane == 0) ctl_store(&ctl[kReadyYe], (int)next);
       }
-      next += cnt;
-      if (lane == 0) ctl_store(&ctl[kReadyYe], (int)next);
+    };
+    follow(0, (own0 < P) ? own0 : P);
+    if (own0 < P && !failed) {
+      // leader phase: the owners publish into the LDS ring only; this wave forwards each
+      // finished record to global memory (agent-scope granules) for the other workgroups
+      for (long f = own0; f < own1; ++f) {
+        while (ctl_load(&ctl[kReadyYe]) <= (int)f) {
+          if (--spins_left <= 0 || ctl_load(&ctl[kBail]) != 0) {
+            failed = true;
+            break;
+          }
+          __builtin_amdgcn_s_sleep(1);
+        }
+        if (failed) break;
+        const double* slot = ring + (size_t)(f % kRing) * TS;
+        u64* rec = a.traj + (size_t)f * TS;
+        if (!(a.debug & 1)) {
+#pragma unroll
+          for (int e = 0; e < EPL; ++e) {
+            const int idx = lane + 64 * e;
+            if (idx < TS) traj_store(rec + idx, slot[idx]);
+          }
+        }
+        if (lane == 0) ctl_store(&ctl[kFwd], (int)f);
+      }
+      if (!failed) follow(own1, P);
     }
     if (failed && lane == 0) {
       __hip_atomic_store(a.status, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);

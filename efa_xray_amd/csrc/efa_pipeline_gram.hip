@@ -210,95 +210,99 @@ __global__ __launch_bounds__(kGT) void k_pipe_gram(const PipeArgs a) {
   // wave 7: loader (follower mode) / forwarder (leader mode)
   // ======================================================================================
   if (wave == 7) {
-    long next = 0;
+    // Three phases, each its own loop: follow the records before the block, forward the block, follow the
+    // rest.  (As ONE loop the compiler merged the pending-load state of the poll path into the forward
+    // path and waited vmcnt(0) per forwarded record, i.e. for the previous record's store to reach
+    // memory: ~1400 cycles per ob, which bounded the whole kernel.)
     bool failed = false;
     int barriers_left = leads ? 3 : 0;
-    while (next < P && !failed) {
-      if (leads && next == own0) {
-        __syncthreads();  // B1: the vector waves have parked their rows in the tile
-        form_gram();
-        if (a.loc_mode != 0) {  // this block's 64 x 64 corner of the obs-obs taper
-          for (int i = lane; i < kRowsWG * kRowsWG; i += 64) {
-            const long kg = own0 + (i >> 6), rg = own0 + (i & 63);
-            tw_s[i] = (kg < P && rg < R) ? a.tw[(size_t)kg * R + rg] : 1.0;
-          }
-        }
-        __syncthreads();  // B2: G and the taper corner are complete
-        barriers_left = 1;
-        for (long f = own0; f < own1 && !failed; ++f) {
-          if (!wait2_gt(&ctl[cReady], (int)f, &ctl[cSReady], (int)(f - own0), true)) {
-            failed = true;
-            break;
-          }
-          const double* slot = ring + (size_t)(f % kRingG) * TS;
-          const double* sc = s_sc + (size_t)(f - own0) * 8;
-          u64* rec = a.traj + (size_t)f * TS;
+    auto follow = [&](long next, const long limit) {
+      while (next < limit && !failed) {
+        const int nrec = (int)((limit - next < kPollG) ? (limit - next) : kPollG);
+        u64 v[kPollG][EPL];
+#pragma unroll
+        for (int d = 0; d < kPollG; ++d) {
+          const long kk = next + ((d < nrec) ? d : nrec - 1);
+          const u64* rec = a.traj + (size_t)kk * TS;
 #pragma unroll
           for (int e = 0; e < EPL; ++e) {
             const int idx = lane + 64 * e;
-            if (idx < TS) g_traj_store(rec + idx, idx < PAD ? slot[idx] : sc[idx - PAD]);
+            v[d][e] = g_traj_load(rec + (idx < TS ? idx : TS - 1));
           }
-          if (lane == 0) g_ctl_set(&ctl[cFwd], (int)f);
-          EFA_GSTAMP(lane == 0, f, 7);
         }
-        __syncthreads();  // B3: done with the pivot's records
-        barriers_left = 0;
-        next = own1;
-        continue;
-      }
-      const long limit = (next < own0) ? ((own0 < P) ? own0 : P) : P;
-      const int nrec = (int)((limit - next < kPollG) ? (limit - next) : kPollG);
-      u64 v[kPollG][EPL];
+        int cnt = 0;
 #pragma unroll
-      for (int d = 0; d < kPollG; ++d) {
-        const long kk = next + ((d < nrec) ? d : nrec - 1);
-        const u64* rec = a.traj + (size_t)kk * TS;
+        for (int d = 0; d < kPollG; ++d) {
+          bool ok = true;
+#pragma unroll
+          for (int e = 0; e < EPL; ++e) ok = ok && (v[d][e] != kTrajSentinel);
+          if (cnt == d && d < nrec && __all(ok)) cnt = d + 1;
+        }
+        if (cnt == 0) {
+          if (--budget <= 0 || __hip_atomic_load(a.status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) failed = true;
+          __builtin_amdgcn_s_sleep(2);
+          continue;
+        }
+        const long need = next + cnt - 1 - kRingG;  // slots are recycled only once every vector wave consumed them
+        if (need >= 0) {
+          for (;;) {
+            int mn = g_ctl_lane(&ctl[cProg + (lane & 3)]);
+            mn = min(mn, __builtin_amdgcn_mov_dpp(mn, 0xB1, 0xF, 0xF, true));
+            mn = min(mn, __builtin_amdgcn_mov_dpp(mn, 0x4E, 0xF, 0xF, true));
+            if (__builtin_amdgcn_readfirstlane(mn) >= (int)need) break;
+            if (--budget <= 0 || g_ctl(&ctl[cBail]) != 0) {
+              failed = true;
+              break;
+            }
+          }
+          if (failed) break;
+        }
+#pragma unroll
+        for (int d = 0; d < kPollG; ++d) {
+          if (d < cnt) {
+            double* slot = ring + (size_t)((next + d) % kRingG) * TS;
+#pragma unroll
+            for (int e = 0; e < EPL; ++e) {
+              const int idx = lane + 64 * e;
+              if (idx < TS) slot[idx] = __longlong_as_double((long long)v[d][e]);
+            }
+          }
+        }
+        next += cnt;
+        if (lane == 0) g_ctl_set(&ctl[cReady], (int)next);
+      }
+    };
+    follow(0, (own0 < P) ? own0 : P);
+    if (leads && !failed) {
+      __syncthreads();  // B1: the vector waves have parked their rows in the tile
+      form_gram();
+      if (a.loc_mode != 0) {  // this block's 64 x 64 corner of the obs-obs taper
+        for (int i = lane; i < kRowsWG * kRowsWG; i += 64) {
+          const long kg = own0 + (i >> 6), rg = own0 + (i & 63);
+          tw_s[i] = (kg < P && rg < R) ? a.tw[(size_t)kg * R + rg] : 1.0;
+        }
+      }
+      __syncthreads();  // B2: G and the taper corner are complete
+      barriers_left = 1;
+      for (long f = own0; f < own1; ++f) {
+        if (!wait2_gt(&ctl[cReady], (int)f, &ctl[cSReady], (int)(f - own0), true)) {
+          failed = true;
+          break;
+        }
+        const double* slot = ring + (size_t)(f % kRingG) * TS;
+        const double* sc = s_sc + (size_t)(f - own0) * 8;
+        u64* rec = a.traj + (size_t)f * TS;
 #pragma unroll
         for (int e = 0; e < EPL; ++e) {
           const int idx = lane + 64 * e;
-          v[d][e] = g_traj_load(rec + (idx < TS ? idx : TS - 1));
+          if (idx < TS) g_traj_store(rec + idx, idx < PAD ? slot[idx] : sc[idx - PAD]);
         }
+        if (lane == 0) g_ctl_set(&ctl[cFwd], (int)f);
+        EFA_GSTAMP(lane == 0, f, 7);
       }
-      int cnt = 0;
-#pragma unroll
-      for (int d = 0; d < kPollG; ++d) {
-        bool ok = true;
-#pragma unroll
-        for (int e = 0; e < EPL; ++e) ok = ok && (v[d][e] != kTrajSentinel);
-        if (cnt == d && d < nrec && __all(ok)) cnt = d + 1;
-      }
-      if (cnt == 0) {
-        if (--budget <= 0 || __hip_atomic_load(a.status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) failed = true;
-        __builtin_amdgcn_s_sleep(2);
-        continue;
-      }
-      const long need = next + cnt - 1 - kRingG;  // slots are recycled only once every vector wave consumed them
-      if (need >= 0) {
-        for (;;) {
-          int mn = g_ctl_lane(&ctl[cProg + (lane & 3)]);
-          mn = min(mn, __builtin_amdgcn_mov_dpp(mn, 0xB1, 0xF, 0xF, true));
-          mn = min(mn, __builtin_amdgcn_mov_dpp(mn, 0x4E, 0xF, 0xF, true));
-          if (__builtin_amdgcn_readfirstlane(mn) >= (int)need) break;
-          if (--budget <= 0 || g_ctl(&ctl[cBail]) != 0) {
-            failed = true;
-            break;
-          }
-        }
-        if (failed) break;
-      }
-#pragma unroll
-      for (int d = 0; d < kPollG; ++d) {
-        if (d < cnt) {
-          double* slot = ring + (size_t)((next + d) % kRingG) * TS;
-#pragma unroll
-          for (int e = 0; e < EPL; ++e) {
-            const int idx = lane + 64 * e;
-            if (idx < TS) slot[idx] = __longlong_as_double((long long)v[d][e]);
-          }
-        }
-      }
-      next += cnt;
-      if (lane == 0) g_ctl_set(&ctl[cReady], (int)next);
+      __syncthreads();  // B3: done with the pivot's records
+      barriers_left = 0;
+      if (!failed) follow(own1, P);
     }
     if (failed && lane == 0) give_up();
     for (; barriers_left > 0; --barriers_left) __syncthreads();  // never leave the others at a barrier
@@ -365,6 +369,19 @@ __global__ __launch_bounds__(kGT) void k_pipe_gram(const PipeArgs a) {
           if (lane == 0) give_up();
           bailed = true;
           break;
+        }
+        if (EFA_EXP(2048)) {  // TIMING EXPERIMENT: no arithmetic on the chain at all, only the protocol
+          s_km[kk * kRowsWG + lane] = 0.0;
+          s_gk[kk * kRowsWG + lane] = make_double2(g, 0.0);
+          if (lane == 0) {
+            double2* sc = reinterpret_cast<double2*>(s_sc + (size_t)kk * 8);
+            sc[0] = make_double2(0.0, 0.0);
+            sc[1] = make_double2(0.0, 1.0);
+            sc[2] = make_double2(0.5, 1.0);
+            sc[3] = make_double2(1.0, 1.0);
+            g_ctl_set(&ctl[cSReady], kk + 1);
+          }
+          continue;
         }
         const double Gkk = rl(g, kk), muk = rl(mu, kk), xmk = rl(xmv, kk);
         const double mu2 = muk * muk;

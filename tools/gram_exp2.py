@@ -14,7 +14,8 @@ HX = rng.standard_normal((P, M)) * 3
 val = HX.mean(axis=1) + rng.standard_normal(P); err = np.ones(P); asm = np.ones(P, bool)
 ctx.set_option("timing", 1); ctx.set_option("pipeline", 1)
 for name, gram, bits in (("classic", 0, 0), ("gram full", 1, 0), ("gram, no helper FMAs", 1, 16), ("gram, no vector work", 1, 96),
-                         ("gram, pivot only", 1, 112), ("gram, followers idle", 1, 1024), ("gram, pivot only + followers idle", 1, 112 | 1024)):
+                         ("gram, pivot only", 1, 112), ("gram, followers idle", 1, 1024), ("gram, pivot only + followers idle", 1, 112 | 1024),
+                         ("gram, protocol only", 1, 112 | 2048), ("gram, protocol only + followers idle", 1, 112 | 1024 | 2048)):
     ctx.set_option("gram", gram); ctx.set_option("pipe_debug", bits)
     ts = []
     for _ in range(4):

@@ -8,7 +8,7 @@ from efa_xray_amd import _lib
 ctx = _lib.get_context(0)
 M, P = 100, 512
 rng = np.random.default_rng(0)
-ctx.set_option("path", 1); ctx.set_option("pipeline", 1); ctx.set_option("gram", 1); ctx.set_option("pipe_debug", 4)
+ctx.set_option("path", 1); ctx.set_option("pipeline", 1); ctx.set_option("gram", 1); ctx.set_option("pipe_debug", 4 | int(os.environ.get("EFA_EXP_BITS", "0")))
 HX = rng.standard_normal((P, M)) * 3
 val = HX.mean(axis=1) + rng.standard_normal(P); err = np.ones(P); asm = np.ones(P, bool)
 for _ in range(2):

@@ -17,10 +17,10 @@ __device__ __forceinline__ void ctl_set(int* p, int v) {
 }
 // MODE bit 0: LDS publication + reads as in the kernel; bit 1: other waves poll (s_sleep 1); bit 2: pollers do not sleep;
 // bit 3: s_setprio(3) for the pivot wave
-template <int MODE>
+template <int MODE, int HI = 0>
 __global__ void k(int iters, double* out, unsigned long long* cyc) {
   extern __shared__ double lds[];
-  double* s_km = lds;                 // [64][64]
+  double* s_km = lds + (HI ? 10240 : 0);                 // [64][64]
   double2* s_gk = reinterpret_cast<double2*>(lds + 4096);  // [64][64]
   double* s_sc = lds + 4096 + 8192;   // [64][8]
   double* G_s = s_sc + 512;           // [64][64]
@@ -107,7 +107,7 @@ int main() {
   hipMalloc(&out, 8192); hipMalloc(&cyc, 8);
   unsigned long long c;
   const int iters = 20000;
-  const size_t lds = (4096 + 8192 + 512 + 4096 + 192) * 8 + 64;
+  size_t lds = (4096 + 8192 + 512 + 4096 + 192) * 8 + 64;
 #define RUN(MODE, THREADS, NAME) \
   hipFuncSetAttribute(reinterpret_cast<const void*>(&k<MODE>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
   hipLaunchKernelGGL(k<MODE>, dim3(1), dim3(THREADS), lds, 0, iters, out, cyc); hipDeviceSynchronize(); \
@@ -119,5 +119,13 @@ int main() {
   RUN(11, 512, "chain + LDS, 7 polling waves (s_sleep 1), setprio 3");
   RUN(15, 512, "chain + LDS, 7 polling waves (no sleep), setprio 3");
   RUN(3, 128, "chain + LDS, 1 polling wave (s_sleep 1)");
+  lds = 150 * 1024;
+  RUN(1, 64, "chain + LDS, one wave, 150 KB LDS allocated");
+  RUN(3, 512, "chain + LDS, 7 polling waves, 150 KB LDS allocated");
+#define RUNH(MODE, THREADS, NAME) \
+  hipFuncSetAttribute(reinterpret_cast<const void*>(&k<MODE, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+  hipLaunchKernelGGL((k<MODE, 1>), dim3(1), dim3(THREADS), lds, 0, iters, out, cyc); hipDeviceSynchronize(); \
+  hipMemcpy(&c, cyc, 8, hipMemcpyDeviceToHost); printf("%-60s %.1f cyc/step\n", NAME, c / (double)iters);
+  RUNH(1, 64, "chain + LDS, one wave, arrays above 80 KB");
   return 0;
 }
