@@ -79,7 +79,7 @@ struct efa_ctx {
   long obs_batch = 64;
   long path = EFA_PATH_AUTO;
   long timing = 0;
-  long use_gram = 0;       // Gram-space leader for the persistent kernel (falls back to the vector chain)
+  long use_gram = 1;       // Gram-space leader for the persistent kernel (falls back to the vector chain)
   long use_pipeline = 1;   // persistent Phase-A kernel when it applies (else per-batch kernels)
   long spin_limit = 4000000;
   long pipe_debug = 0;

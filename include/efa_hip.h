@@ -77,8 +77,8 @@ int efa_ctx_set_stream(efa_ctx *ctx, void *hip_stream);
 /* options: "obs_batch" (obs fused per sweep launch, 1..64, default 64),
  *          "path" (EFA_PATH_*), "timing" (0/1), "pipeline" (1: run Phase A as
  *          one persistent launch when it applies, 0: per-batch kernels),
- *          "gram" (1: the persistent launch leads each 64-ob block in Gram space,
- *          falling back to the vector chain if its cancellation guard trips),
+ *          "gram" (default 1: the persistent launch leads each 64-ob block in Gram
+ *          space, falling back to the vector chain if its cancellation guard trips),
  *          "spin_limit" (bound of the pipeline's in-kernel polls),
  *          "gc_onepass" (1: localised state sweep in one pass with per-column-block
  *          active lists, 0: per-batch taper tables), "own_stream" (see above);

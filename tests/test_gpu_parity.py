@@ -16,6 +16,9 @@ pytestmark = pytest.mark.gpu
 RTOL = 1e-10
 
 
+GRAM_DEFAULT = 1  # library default of the "gram" option (Phase-A leader in Gram space)
+
+
 def _ctx():
     from efa_xray_amd import _lib
     return _lib.get_context(0)
@@ -116,7 +119,7 @@ def test_phase_a_per_batch_kernels_and_pipeline_fallback(name):
             assert np.array_equal(diag["assimilated"], g["assimilated"])
     finally:
         ctx.set_option("pipeline", 1)
-        ctx.set_option("gram", 0)
+        ctx.set_option("gram", GRAM_DEFAULT)
         ctx.set_option("spin_limit", 4000000)
         ctx.set_option("path", 0)
 
@@ -220,12 +223,14 @@ def _run_oracle(c):
     return xam, Xap, diag
 
 
-def _run_hip(c, path="auto", batch=32, pipeline=1):
-    """pipeline: 0 per-batch kernels, 1 persistent kernel (vector chain), 2 persistent kernel (Gram leader)"""
+def _run_hip(c, path="auto", batch=32, pipeline=None):
+    """pipeline: None library default, 0 per-batch kernels, 1 persistent kernel (vector chain),
+    2 persistent kernel (Gram leader)"""
     ctx = _ctx()
     ctx.set_option("obs_batch", batch)
-    ctx.set_option("pipeline", 1 if pipeline else 0)
-    ctx.set_option("gram", 1 if pipeline == 2 else 0)
+    if pipeline is not None:
+        ctx.set_option("pipeline", 1 if pipeline else 0)
+        ctx.set_option("gram", 1 if pipeline == 2 else 0)
     ctx.set_option("path", {"auto": 0, "sweep": 1, "transform": 2}[path])
     xbm, Xbp = orc.format_prior_state(c["X"], c["HX"])
     kw = dict(loc_mode=0)
@@ -236,7 +241,7 @@ def _run_hip(c, path="auto", batch=32, pipeline=1):
     ctx.set_option("path", 0)
     ctx.set_option("obs_batch", 64)
     ctx.set_option("pipeline", 1)
-    ctx.set_option("gram", 0)
+    ctx.set_option("gram", GRAM_DEFAULT)
     return xbm, Xbp, diag
 
 
@@ -261,6 +266,32 @@ def test_seeded_shapes_vs_oracle(N, M, P, loc):
         for key in ("prior_mean", "prior_var", "post_mean", "post_var"):
             assert_parity(h_diag[key], diag[key], key)
         assert np.array_equal(h_diag["assimilated"], diag["assimilated"])
+
+
+def test_gram_leader_cancellation_guard_falls_back():
+    """Near-exact, repeated observations of one quantity collapse the variance of the rows that follow by
+    far more than 1e3 inside one 64-ob block: the Gram-space leader must notice (its downdated G_kk has
+    lost digits), bail out, and the vector-chain pipeline must deliver the reference's numbers."""
+    c = _random_case(77, 300, 24, 90, False, frac_assim=1.0)
+    c["HX"][1:40] = c["HX"][0] + 1e-4 * np.random.default_rng(3).standard_normal((39, 24))  # 40 near-copies of ob 0
+    c["val"][:40] = c["HX"][0].mean() + 0.1
+    c["err"][:40] = 1e-8
+    xam, Xap, diag = _run_oracle(c)
+    ctx = _ctx()
+    h_xam, h_Xap, h_diag = _run_hip(c, path="sweep", pipeline=2)
+    assert_parity(h_xam, xam, "xam")
+    assert_parity(h_Xap, Xap, "Xap")
+    for key in ("prior_mean", "prior_var", "post_mean", "post_var"):
+        assert_parity(h_diag[key], diag[key], key)
+    # and the guard did trip: the last Phase A was done by the vector-chain kernel
+    ctx.set_option("gram", 1)
+    ctx.set_option("path", 1)
+    xbm, Xbp = orc.format_prior_state(c["X"], c["HX"])
+    ctx.ensrf_update_host(xbm, Xbp, c["N"], c["val"], c["err"], c["asm"], loc_mode=0)
+    kind = ctx.get_option("phase_a_kind")
+    ctx.set_option("gram", GRAM_DEFAULT)
+    ctx.set_option("path", 0)
+    assert kind == 1
 
 
 def test_edge_cases_no_obs_and_none_assimilated():
