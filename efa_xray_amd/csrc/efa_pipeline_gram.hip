@@ -113,6 +113,8 @@ __global__ __launch_bounds__(kGT) void k_pipe_gram(const PipeArgs a) {
   double* s_sc = U + 2 * kRowsWG * kRowsWG;
 
   const int tid = threadIdx.x;
+  // wave roles: 0-3 vector, 4 pivot, 5-6 helpers, 7 loader (pairing the pivot with the loader on one SIMD
+  // instead, by permuting the roles, measured 3% slower)
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
   const int M = a.M;
   const long P = a.P, R = a.R;
@@ -345,7 +347,6 @@ __global__ __launch_bounds__(kGT) void k_pipe_gram(const PipeArgs a) {
       const bool gc = a.loc_mode != 0;
       const double* twp = gc ? tw_s + lane : pv + lane;  // always a valid address: the load is unconditional
       double twn = twp[0];
-      __builtin_amdgcn_s_setprio(3);
 #ifdef EFA_PIPE_STAMPS
       const bool seg = (a.debug & 256) != 0 && a.dbg != nullptr;
 #else
@@ -471,7 +472,6 @@ __global__ __launch_bounds__(kGT) void k_pipe_gram(const PipeArgs a) {
         for (int i = 0; i < 4; ++i) a.dbg[(size_t)(own0 + i) * 8 + 5] = segsum[i];
       }
       pm[kRowsWG + lane] = xmv;  // obs-space means of all 64 rows after the block, back to the vector waves
-      __builtin_amdgcn_s_setprio(0);
       // diagnostics of this block's obs from the step records (lane = ob)
       double o_pm = 0.0, o_pv = 0.0, o_in = 0.0, o_rd = 0.0, o_be = 0.0, o_km = 0.0;
       if (is_ob && !bailed) {
@@ -507,7 +507,7 @@ __global__ __launch_bounds__(kGT) void k_pipe_gram(const PipeArgs a) {
     // pivot wave through G_s during step kk, a full step before the pivot needs it (the pivot applies
     // the last two steps to it itself), so only the helpers' throughput matters, not their latency
     const int h = wave - kVW - 1;  // 0, 1
-    __builtin_amdgcn_s_setprio(2);
+    __builtin_amdgcn_s_setprio(2);  // measured: 2% faster Phase A with it, 3% slower if the pivot wave is raised too
     double gr[kRowsWG / 2];
 #pragma unroll
     for (int r = 0; r < kRowsWG / 2; ++r) gr[r] = (2 * r + h >= 3) ? G_s[(2 * r + h) * kRowsWG + lane] : 0.0;
