@@ -100,17 +100,16 @@ __global__ __launch_bounds__(kGT) void k_pipe_gram(const PipeArgs a) {
   extern __shared__ __align__(16) double lds[];
   double* ring = lds;                          // [kRingG][TS]   ye rows (+ scalars in follower mode)
   double* G_s = ring + kRingG * TS;            // [64][64]       Gram matrix of the block
-  double* U = G_s + kRowsWG * kRowsWG;         // union: Yt[64][SP]  then  {g, kb}[64][64], sc[64][8]
+  double* U = G_s + kRowsWG * kRowsWG;         // union: Yt[64][SP]  then  {g, kb}[64][64], sc[64][4]
   double* pm = U + UREG;                       // [2][64]        parked row means / obs-space means
   double* pv = pm + 2 * kRowsWG;               // [3][64]        ob value / error / sqrt(error) of the block
   double* tw_s = pv + 3 * kRowsWG;             // [64][64]       taper corner (GC only)
   int* ctl = reinterpret_cast<int*>(tw_s + (a.loc_mode != 0 ? kRowsWG * kRowsWG : 0));  // [16]
   double* Yt = U;
-  // per-step records of the pivot wave.  kmat of step kk goes into row kk of G_s: that row is dead by
-  // then (the pivot holds it in registers, and its helper finished loading its rows before handing it over)
-  double* s_km = G_s;
+  // per-step records of the pivot wave (every LDS instruction on that wave costs the chain ~30 cycles of
+  // issue, so a step publishes as little as possible): one b128 per lane and two by lane 0
   double2* s_gk = reinterpret_cast<double2*>(U);  // [step][row] = {G_kj, kb_j}
-  double* s_sc = U + 2 * kRowsWG * kRowsWG;
+  double* s_sc = U + 2 * kRowsWG * kRowsWG;       // [step][4]   = innov, rden, beta, active
 
   const int tid = threadIdx.x;
   // wave roles: 0-3 vector, 4 pivot, 5-6 helpers, 7 loader (pairing the pivot with the loader on one SIMD
@@ -292,12 +291,13 @@ __global__ __launch_bounds__(kGT) void k_pipe_gram(const PipeArgs a) {
           break;
         }
         const double* slot = ring + (size_t)(f % kRingG) * TS;
-        const double* sc = s_sc + (size_t)(f - own0) * 8;
+        const double* sc = s_sc + (size_t)(f - own0) * 4;
         u64* rec = a.traj + (size_t)f * TS;
 #pragma unroll
         for (int e = 0; e < EPL; ++e) {
-          const int idx = lane + 64 * e;
-          if (idx < TS) g_traj_store(rec + idx, idx < PAD ? slot[idx] : sc[idx - PAD]);
+          const int idx = lane + 64 * e;  // record = ye, then 8 scalars of which the followers read [2..5]
+          const int si = idx - PAD - 2;
+          if (idx < TS) g_traj_store(rec + idx, idx < PAD ? slot[idx] : ((si >= 0 && si < 4) ? sc[si] : 0.0));
         }
         if (lane == 0) g_ctl_set(&ctl[cFwd], (int)f);
         EFA_GSTAMP(lane == 0, f, 7);
@@ -323,8 +323,7 @@ __global__ __launch_bounds__(kGT) void k_pipe_gram(const PipeArgs a) {
       // ---------------- pivot wave: lane j <-> row j of the workgroup ----------------
       // The loop below is the serial chain of the whole filter, and one wave issues in order: every
       // instruction in it costs issue slots, so per-step work is kept to the recurrence itself.
-      // Per-ob constants come from LDS with uniform addresses, diagnostics are reconstructed from the
-      // step records after the loop, and the gain factors are arranged for a short dependent chain:
+      // Per-ob constants come from LDS with uniform addresses, an ob's diagnostics stay in its lane, and the gain factors are arranged for a short dependent chain:
       //   kdenom -> q0 = rsq(kdenom) -> { Newton step of q  ||  beta0 = 1/(1 + sqrt(err) q0) } -> beta
       // with beta = beta0 - beta0^2 sqrt(err) q0 d for q = q0 (1 + d)  (d ~ 1e-8: the d^2 term is < 1 ulp).
       const long obj = own0 + lane;
@@ -339,6 +338,7 @@ __global__ __launch_bounds__(kGT) void k_pipe_gram(const PipeArgs a) {
       // cancellation guard: an assimilated pivot whose G_kk fell below 1e-3 of its value at block start
       const double thr = my_asm ? 1e-3 * G_s[lane * kRowsWG + lane] : -1.0;
       bool bailed = false;
+      double o_pm = 0.0, o_pv = 0.0, o_in = 0.0, o_rd = 0.0, o_be = 0.0, o_km = 0.0;
       double g = G_s[lane];             // row 0
       double g1 = G_s[kRowsWG + lane];  // row 1
       // per-ob constants (and the taper row) are fetched one step ahead: an LDS round trip at the top of a
@@ -372,14 +372,11 @@ __global__ __launch_bounds__(kGT) void k_pipe_gram(const PipeArgs a) {
           break;
         }
         if (EFA_EXP(2048)) {  // TIMING EXPERIMENT: no arithmetic on the chain at all, only the protocol
-          s_km[kk * kRowsWG + lane] = 0.0;
           s_gk[kk * kRowsWG + lane] = make_double2(g, 0.0);
           if (lane == 0) {
-            double2* sc = reinterpret_cast<double2*>(s_sc + (size_t)kk * 8);
-            sc[0] = make_double2(0.0, 0.0);
-            sc[1] = make_double2(0.0, 1.0);
-            sc[2] = make_double2(0.5, 1.0);
-            sc[3] = make_double2(1.0, 1.0);
+            double2* sc = reinterpret_cast<double2*>(s_sc + (size_t)kk * 4);
+            sc[0] = make_double2(0.0, 1.0);
+            sc[1] = make_double2(0.5, 1.0);
             g_ctl_set(&ctl[cSReady], kk + 1);
           }
           continue;
@@ -411,15 +408,20 @@ __global__ __launch_bounds__(kGT) void k_pipe_gram(const PipeArgs a) {
           asm volatile("" ::"v"(kb));
           T1 = __builtin_amdgcn_s_memtime();
         }
-        s_km[kk * kRowsWG + lane] = km;
         s_gk[kk * kRowsWG + lane] = make_double2(g, kb);
         if (lane == 0) {
-          double2* sc = reinterpret_cast<double2*>(s_sc + (size_t)kk * 8);
-          sc[0] = make_double2(xmk, muk);
-          sc[1] = make_double2(innov, rden);
-          sc[2] = make_double2(beta, act ? 1.0 : 0.0);
-          sc[3] = make_double2(__builtin_fma(Gkk, invM, -mu2), Gkk);  // np.var, ddof = 0 (:69)
+          double2* sc = reinterpret_cast<double2*>(s_sc + (size_t)kk * 4);
+          sc[0] = make_double2(innov, rden);
+          sc[1] = make_double2(beta, act ? 1.0 : 0.0);
           g_ctl_set(&ctl[cSReady], kk + 1);
+        }
+        if (lane == kk) {  // this ob's diagnostics stay in its lane
+          o_pm = xmk;                                  // :66
+          o_pv = __builtin_fma(Gkk, invM, -mu2);       // np.var, ddof = 0 (:69, :70)
+          o_in = innov;
+          o_rd = rden;
+          o_be = beta;
+          o_km = km;
         }
         EFA_GSTAMP(lane == 0, own0 + kk, 1);
         if (seg) T2 = __builtin_amdgcn_s_memtime();
@@ -472,17 +474,6 @@ __global__ __launch_bounds__(kGT) void k_pipe_gram(const PipeArgs a) {
         for (int i = 0; i < 4; ++i) a.dbg[(size_t)(own0 + i) * 8 + 5] = segsum[i];
       }
       pm[kRowsWG + lane] = xmv;  // obs-space means of all 64 rows after the block, back to the vector waves
-      // diagnostics of this block's obs from the step records (lane = ob)
-      double o_pm = 0.0, o_pv = 0.0, o_in = 0.0, o_rd = 0.0, o_be = 0.0, o_km = 0.0;
-      if (is_ob && !bailed) {
-        const double* sc = s_sc + (size_t)lane * 8;
-        o_pm = sc[0];   // :66
-        o_in = sc[2];
-        o_rd = sc[3];
-        o_be = sc[4];
-        o_pv = sc[6];   // :70
-        o_km = s_km[lane * kRowsWG + lane];
-      }
       __syncthreads();  // B3
       if (!bailed && g_ctl(&ctl[cBail]) == 0 && is_ob) {
         a.prior_mean[obj] = o_pm;
@@ -538,7 +529,7 @@ __global__ __launch_bounds__(kGT) void k_pipe_gram(const PipeArgs a) {
       EFA_GSTAMP(lane == 0 && h == 0 && (a.debug & 8), own0 + kk, 3);
       const double2* rec = s_gk + kk * kRowsWG;
       const double2 own = rec[lane];
-      const double Gkk = s_sc[kk * 8 + 7];
+      const double Gkk = rl(own.x, kk);
       const double kb = own.y;
       const double t = own.x - kb * Gkk;
       EFA_GSTAMP(lane == 0 && h == ((kk + 1) & 1) && !(a.debug & 8), own0 + kk, 5);
