@@ -527,6 +527,21 @@ __global__ __launch_bounds__(kGT) void k_pipe_gram(const PipeArgs a) {
     for (int kk = 0; kk + 3 < nb; ++kk) {
       if (!wait_gt(&ctl[cSReady], kk, false)) break;
       EFA_GSTAMP(lane == 0 && h == 0 && (a.debug & 8), own0 + kk, 3);
+#ifdef EFA_PIPE_STAMPS
+      if ((a.debug & 4096) && a.dbg != nullptr && h == 1) {  // LDS round-trip latency under the real load
+        unsigned long long t0, t1, t2;
+        int vv;
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t0)::"memory");
+        asm volatile("ds_read_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(vv) : "v"((int)(size_t)0) : "memory");
+        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t1)::"memory");
+        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t2)::"memory");
+        if (lane == 0) {
+          a.dbg[(size_t)(own0 + kk) * 8 + 1] = t1 - t0;  // LDS round trip + one s_memtime round trip
+          a.dbg[(size_t)(own0 + kk) * 8 + 2] = t2 - t1;  // one s_memtime round trip
+        }
+        asm volatile("" ::"v"(vv));
+      }
+#endif
       const double2* rec = s_gk + kk * kRowsWG;
       const double2 own = rec[lane];
       const double Gkk = rl(own.x, kk);

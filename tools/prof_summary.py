@@ -30,7 +30,7 @@ def main():
     lines = []
     stats = max(glob.glob(os.path.join(src, "stats", "*", "*kernel_stats.csv")), key=os.path.getmtime)
     rows = list(csv.DictReader(open(stats)))
-    lines.append("# rocprofv3 --kernel-trace --stats -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline")
+    lines.append("# rocprofv3 --kernel-trace --stats --output-format csv -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline")
     lines.append("# (1 warm-up + 3 timed cycles of the headline workload; durations in microseconds)")
     lines.append("%-34s %6s %12s %12s %7s" % ("kernel", "calls", "avg_us", "total_us", "pct"))
     avg = {}
