@@ -28,7 +28,14 @@ namespace {
 
 typedef double v4f64 __attribute__((ext_vector_type(4)));
 
-constexpr int kThreadsT = 512;  // 8 waves: two per SIMD share the workgroup's LDS copy of [T|w]
+#ifndef EFA_T_WAVES
+#define EFA_T_WAVES 8
+#endif
+#ifndef EFA_T_PREFETCH
+#define EFA_T_PREFETCH 1
+#endif
+constexpr int kThreadsT = 64 * EFA_T_WAVES;  // waves per workgroup, sharing its LDS copy of [T|w]
+constexpr bool kPrefetchT = EFA_T_PREFETCH != 0;
 
 template <int NU>
 struct TShape {
@@ -109,7 +116,7 @@ __global__ __launch_bounds__(kThreadsT) void k_transform(const TransformArgs p) 
         xm4[v] = p.xin[rr < last_row ? rr : last_row];
       }
     }
-    {  // prefetch (the last iteration harmlessly re-reads its own tile)
+    if (kPrefetchT) {  // prefetch (the last iteration harmlessly re-reads its own tile)
       const long r = (next < ntiles ? next : tile) * 16 + n;
       load_tile<NU>(p.Xin, r < last_row ? r : last_row, M, g, an);
     }
@@ -192,8 +199,13 @@ __global__ __launch_bounds__(kThreadsT) void k_transform(const TransformArgs p) 
       }
     }
 
+    if (kPrefetchT) {
 #pragma unroll
-    for (int c = 0; c < 2 * NU; ++c) a[c] = an[c];
+      for (int c = 0; c < 2 * NU; ++c) a[c] = an[c];
+    } else if (next < ntiles) {
+      const long r = next * 16 + n;
+      load_tile<NU>(p.Xin, r < last_row ? r : last_row, M, g, a);
+    }
     tile = next;
   }
 }
@@ -209,7 +221,7 @@ hipError_t transform_launch(const TransformArgs& a, hipStream_t s) {
   }
   const long ntiles = (a.nrows + 15) / 16;
   const int per_cu = (lds <= 80 * 1024) ? 2 : 1;
-  long grid = (ntiles + 7) / 8;
+  long grid = (ntiles + EFA_T_WAVES - 1) / EFA_T_WAVES;
   if (grid > 256L * per_cu) grid = 256L * per_cu;
   if (grid < 1) grid = 1;
   hipLaunchKernelGGL((k_transform<NU, FUSED>), dim3((unsigned)grid), dim3(kThreadsT), lds, s, a);
