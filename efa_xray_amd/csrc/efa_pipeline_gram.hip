@@ -316,6 +316,13 @@ __global__ __launch_bounds__(kGT) void k_pipe_gram(const PipeArgs a) {
   // ======================================================================================
   if (wave >= kVW) {
     if (!leads) return;
+    // the block's ob constants are fetched now, while the wave waits for its block anyway (after B2 the
+    // global-memory round trip would sit on the hand-over between workgroups)
+    const bool pre_ob = lane < nb;
+    const double pre_err = (wave == kVW && pre_ob) ? a.ob_error[own0 + lane] : 1.0;
+    const double pre_val = (wave == kVW && pre_ob) ? a.ob_value[own0 + lane] : 0.0;
+    const bool pre_asm = (wave == kVW && pre_ob) ? (a.ob_assim[own0 + lane] != 0) : false;
+    const double pre_sq = sqrt(pre_err);
     __syncthreads();  // B1
     form_gram();
     __syncthreads();  // B2
@@ -329,11 +336,10 @@ __global__ __launch_bounds__(kGT) void k_pipe_gram(const PipeArgs a) {
       const long obj = own0 + lane;
       const bool is_ob = lane < nb;
       double mu = pm[lane], xmv = pm[kRowsWG + lane];
-      const double err = is_ob ? a.ob_error[obj] : 1.0;
-      const bool my_asm = is_ob && a.ob_assim[obj] != 0;
-      pv[lane] = is_ob ? a.ob_value[obj] : 0.0;
-      pv[kRowsWG + lane] = err;
-      pv[2 * kRowsWG + lane] = sqrt(err);
+      const bool my_asm = pre_asm;
+      pv[lane] = pre_val;
+      pv[kRowsWG + lane] = pre_err;
+      pv[2 * kRowsWG + lane] = pre_sq;
       const u64 asm_mask = __ballot(my_asm);
       // cancellation guard: an assimilated pivot whose G_kk fell below 1e-3 of its value at block start
       const double thr = my_asm ? 1e-3 * G_s[lane * kRowsWG + lane] : -1.0;
