@@ -22,60 +22,85 @@ namespace {
 
 constexpr int kBlkCols = 16;  // columns per block == rows per wave in the quad layout
 
-// One workgroup per column block; thread t: column c = t & 15, observation slot o = t >> 4
-// (16 observations per chunk, visited in ascending order).  FILL = false: count only.
+// One WAVE per column block: lane l = (column c = l & 15, observation slot o = l >> 4), four
+// observations per step in ascending order.  Everything the list needs is wave-local (ballot +
+// a running count in a scalar register), so the loop has no workgroup barrier; the exact
+// latitude rejection keeps the trigonometry to the few observations near the block.
+// FILL = false: count only.
+constexpr int kBuildWaves = 4;  // column blocks per workgroup
 template <bool FILL>
-__global__ __launch_bounds__(256) void k_gc_build(long ncol, long P, const double* __restrict__ glat,
-                                                  const double* __restrict__ glon,
-                                                  const double* __restrict__ ob_lat,
-                                                  const double* __restrict__ ob_lon,
-                                                  const double* __restrict__ ob_hw,
-                                                  const double* __restrict__ coef, int* __restrict__ cnt,
-                                                  const long* __restrict__ off, int* __restrict__ idx,
-                                                  double* __restrict__ wts) {
-  __shared__ int flags[16];
-  __shared__ long running;
-  const long b = blockIdx.x;
-  const int t = threadIdx.x;
-  const int c = t & 15, o = t >> 4;
+__global__ __launch_bounds__(64 * kBuildWaves) void k_gc_build(long ncol, long nblk, long P,
+                                                               const double* __restrict__ glat,
+                                                               const double* __restrict__ glon,
+                                                               const double* __restrict__ ob_lat,
+                                                               const double* __restrict__ ob_lon,
+                                                               const double* __restrict__ ob_hw,
+                                                               const double* __restrict__ coef, int* __restrict__ cnt,
+                                                               const long* __restrict__ off, int* __restrict__ idx,
+                                                               double* __restrict__ wts) {
+  const int lane = threadIdx.x & 63;
+  const long b = (long)blockIdx.x * kBuildWaves + (threadIdx.x >> 6);
+  if (b >= nblk) return;
+  const int c = lane & 15, o = lane >> 4;
   const long col = b * kBlkCols + c;
   const bool col_ok = col < ncol;
   const double la = col_ok ? glat[col] : 0.0, lo = col_ok ? glon[col] : 0.0;
-  if (t == 0) running = FILL ? off[b] : 0;
-  __syncthreads();
-  for (long k0 = 0; k0 < P; k0 += 16) {
-    const long k = k0 + o;
-    double w = 0.0;
-    if (k < P && col_ok && coef[k * kCoefStride + 3] != 0.0) {
-      // cheap exact rejection: the great-circle distance is at least R*|dlat|; beyond 2 x halfwidth
-      // the Gaspari-Cohn weight is exactly 0, so the trigonometry can be skipped
-      const double hw = ob_hw[k], olat = ob_lat[k];
-      if (kEarthRadiusKm * fabs(radians(olat - la)) <= 2.0 * fabs(hw) * (1.0 + 1e-9) || !(hw == hw))
-        w = gaspari_cohn(distance_to_point_km(la, lo, olat, ob_lon[k]), hw);
-    }
-    const unsigned long long bal = __ballot(w != 0.0);
-    const int g = (t & 63) >> 4;
-    const bool any = ((bal >> (16 * g)) & 0xFFFFull) != 0ull;
-    if (c == 0) flags[o] = any ? 1 : 0;
-    __syncthreads();
-    int before = 0, total = 0;
+  // latitude range of the block's columns (the same in every lane)
+  double la_lo = col_ok ? la : 1e300, la_hi = col_ok ? la : -1e300;
 #pragma unroll
-    for (int i = 0; i < 16; ++i) {
-      const int f = flags[i];
-      before += (i < o) ? f : 0;
-      total += f;
-    }
-    const long base = running;
-    if (FILL && any) {
-      const long e = base + before;
-      if (c == 0) idx[e] = (int)k;
-      wts[e * kBlkCols + c] = w;
-    }
-    __syncthreads();
-    if (t == 0) running = base + total;
-    __syncthreads();
+  for (int m = 1; m < 64; m <<= 1) {
+    la_lo = fmin(la_lo, __shfl_xor(la_lo, m, 64));
+    la_hi = fmax(la_hi, __shfl_xor(la_hi, m, 64));
   }
-  if (!FILL && t == 0) cnt[b] = (int)running;
+  long running = FILL ? off[b] : 0;
+  for (long k0 = 0; k0 < P; k0 += 64) {
+    // 64 observations at once, lane <-> observation: the great-circle distance to ANY column of the
+    // block is at least R * (latitude gap to the block's range); beyond 2 x halfwidth the
+    // Gaspari-Cohn weight is exactly 0, so most observations never reach the trigonometry
+    unsigned long long cand;
+    {
+      const long k = k0 + lane;
+      bool cnd = false;
+      if (k < P && coef[k * kCoefStride + 3] != 0.0) {
+        const double hw = ob_hw[k], olat = ob_lat[k];
+        const double gap = fmax(0.0, fmax(olat - la_hi, la_lo - olat));
+        cnd = (kEarthRadiusKm * radians(gap) <= 2.0 * fabs(hw) * (1.0 + 1e-9)) || !(hw == hw);
+      }
+      cand = __ballot(cnd);
+    }
+    while (cand != 0ull) {  // four candidates per step, ascending
+      int kb[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        kb[i] = (cand != 0ull) ? (int)__builtin_ctzll(cand) : -1;
+        if (cand != 0ull) cand &= cand - 1;
+      }
+      const int bit = (o == 0) ? kb[0] : (o == 1) ? kb[1] : (o == 2) ? kb[2] : kb[3];
+      const long k = k0 + bit;
+      double w = 0.0;
+      if (bit >= 0 && col_ok) {
+        const double hw = ob_hw[k], olat = ob_lat[k];
+        if (kEarthRadiusKm * fabs(radians(olat - la)) <= 2.0 * fabs(hw) * (1.0 + 1e-9) || !(hw == hw))
+          w = gaspari_cohn(distance_to_point_km(la, lo, olat, ob_lon[k]), hw);
+      }
+      const unsigned long long bal = __ballot(w != 0.0);
+      if (bal == 0ull) continue;  // wave-uniform
+      int before = 0, total = 0;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int f = ((bal >> (16 * i)) & 0xFFFFull) != 0ull ? 1 : 0;
+        before += (i < o) ? f : 0;
+        total += f;
+      }
+      if (FILL && ((bal >> (16 * o)) & 0xFFFFull) != 0ull) {
+        const long e = running + before;
+        if (c == 0) idx[e] = (int)k;
+        wts[e * kBlkCols + c] = w;
+      }
+      running += total;
+    }
+  }
+  if (!FILL && lane == 0) cnt[b] = (int)running;
 }
 
 constexpr int kChunk = 32;  // active observations staged in LDS at a time
@@ -198,8 +223,8 @@ hipError_t launch_gc_count(long ncol, long P, const double* glat, const double* 
                            const double* ob_lon, const double* ob_hw, const double* coef, int* cnt, hipStream_t s) {
   const long nblk = gc_num_blocks(ncol);
   if (nblk <= 0) return hipSuccess;
-  hipLaunchKernelGGL((k_gc_build<false>), dim3((unsigned)nblk), dim3(256), 0, s, ncol, P, glat, glon, ob_lat, ob_lon,
-                     ob_hw, coef, cnt, nullptr, nullptr, nullptr);
+  hipLaunchKernelGGL((k_gc_build<false>), dim3((unsigned)((nblk + kBuildWaves - 1) / kBuildWaves)), dim3(64 * kBuildWaves), 0,
+                     s, ncol, nblk, P, glat, glon, ob_lat, ob_lon, ob_hw, coef, cnt, nullptr, nullptr, nullptr);
   return hipGetLastError();
 }
 
@@ -208,8 +233,8 @@ hipError_t launch_gc_fill(long ncol, long P, const double* glat, const double* g
                           double* wts, hipStream_t s) {
   const long nblk = gc_num_blocks(ncol);
   if (nblk <= 0) return hipSuccess;
-  hipLaunchKernelGGL((k_gc_build<true>), dim3((unsigned)nblk), dim3(256), 0, s, ncol, P, glat, glon, ob_lat, ob_lon,
-                     ob_hw, coef, nullptr, off, idx, wts);
+  hipLaunchKernelGGL((k_gc_build<true>), dim3((unsigned)((nblk + kBuildWaves - 1) / kBuildWaves)), dim3(64 * kBuildWaves), 0,
+                     s, ncol, nblk, P, glat, glon, ob_lat, ob_lon, ob_hw, coef, nullptr, off, idx, wts);
   return hipGetLastError();
 }
 
