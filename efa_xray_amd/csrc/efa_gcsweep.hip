@@ -110,7 +110,7 @@ constexpr int kChunk = 32;  // active observations staged in LDS at a time
 // rows, tapers, coefficients), so the per-lane traffic of the inner loop is LDS only.  Fetching ye
 // per lane straight from L2 made the kernel vector-memory-issue bound (10 x 1 KB requests per
 // wave and observation through one 64 B/clk path per CU).
-template <int NC, bool VEC, bool FUSED>
+template <int NC, bool VEC, bool FUSED, int RPL>
 __global__ __launch_bounds__(256) void k_sweep_gc(const GcSweepArgs a) {
   constexpr int L = 4;
   constexpr int S = 2 * L * NC;  // padded ye row (doubles)
@@ -127,23 +127,34 @@ __global__ __launch_bounds__(256) void k_sweep_gc(const GcSweepArgs a) {
   const double rM1 = 1.0 / (double)(M - 1);
   const long e0 = a.off[b], e1 = a.off[b + 1];
 
-  for (long lead0 = 0; lead0 < a.n_lead; lead0 += 4) {
-    const long lead = lead0 + wave;
-    const bool live = col_ok && lead < a.n_lead;
-    const long row = lead * a.ncol + col;
-    double x[2 * NC];
-    double xm = 0.0;
-    if (live) {
-      load_row<L, NC, VEC>(a.Xin + (size_t)row * M, M, j, x);
-      if (!FUSED) xm = a.xin[row];
-    } else {
+  // A quad holds RPL rows of the SAME column (slabs lead, lead + 4, ...): they share the taper and
+  // every ye row read from LDS, which is what bounds this kernel (the quad layout delivers each ye
+  // row once per quad), and a staged chunk serves 4 RPL slabs instead of 4.
+  for (long lead0 = 0; lead0 < a.n_lead; lead0 += 4 * RPL) {
+    double x[RPL][2 * NC];
+    double xm[RPL];
+    bool live[RPL];
+    long row[RPL];
+    bool any_live = false;
 #pragma unroll
-      for (int c = 0; c < 2 * NC; ++c) x[c] = 0.0;
-    }
-    if (FUSED) {  // prior members in: remove the ensemble mean (assimilation.py:146-147)
-      xm = group_rowsum<L, NC>(x) / (double)M;
+    for (int q = 0; q < RPL; ++q) {
+      const long lead = lead0 + wave + 4 * q;
+      live[q] = col_ok && lead < a.n_lead;
+      any_live = any_live || live[q];
+      row[q] = lead * a.ncol + col;
+      xm[q] = 0.0;
+      if (live[q]) {
+        load_row<L, NC, VEC>(a.Xin + (size_t)row[q] * M, M, j, x[q]);
+        if (!FUSED) xm[q] = a.xin[row[q]];
+      } else {
 #pragma unroll
-      for (int c = 0; c < 2 * NC; ++c) x[c] -= xm;  // padding slots never reach the output or the dot
+        for (int c = 0; c < 2 * NC; ++c) x[q][c] = 0.0;
+      }
+      if (FUSED) {  // prior members in: remove the ensemble mean (assimilation.py:146-147)
+        xm[q] = group_rowsum<L, NC>(x[q]) / (double)M;
+#pragma unroll
+        for (int c = 0; c < 2 * NC; ++c) x[q][c] -= xm[q];  // padding slots never reach the output or the dot
+      }
     }
     for (long c0 = e0; c0 < e1; c0 += kChunk) {
       const int ne = (int)((e1 - c0 < kChunk) ? (e1 - c0) : kChunk);
@@ -171,30 +182,36 @@ __global__ __launch_bounds__(256) void k_sweep_gc(const GcSweepArgs a) {
         cf_s[tid] = a.coef[(size_t)a.idx[c0 + ee] * kCoefStride + q];
       }
       __syncthreads();
-      // ---- apply the chunk to this wave's 16 rows
+      // ---- apply the chunk to this wave's 16 RPL rows
       for (int ee = 0; ee < ne; ++ee) {
-        const double w = live ? wt_s[ee * kBlkCols + r] : 0.0;
-        if (__ballot(w != 0.0) == 0ull) continue;  // none of this wave's rows (dead slab / zero taper)
+        const double w = any_live ? wt_s[ee * kBlkCols + r] : 0.0;
+        if (__ballot(w != 0.0) == 0ull) continue;  // none of this wave's rows (dead slabs / zero taper)
         double y[2 * NC];
         lds_read_row<L, NC>(ye_s + ee * S, j, y);
         const double* ck = cf_s + ee * 4;
-        const double dot = group_dot<L, NC>(x, y);
-        double kc = dot * rM1;         // :95
-        kc = w * kc;                   // :115
-        const double km = kc * ck[1];  // :119
-        xm = xm + km * ck[0];          // :130
-        const double kb = ck[2] * km;  // :136
 #pragma unroll
-        for (int c = 0; c < 2 * NC; ++c) x[c] = __builtin_fma(-kb, y[c], x[c]);  // :141
+        for (int q = 0; q < RPL; ++q) {
+          const double dot = group_dot<L, NC>(x[q], y);
+          double kc = dot * rM1;            // :95
+          kc = (live[q] ? w : 0.0) * kc;    // :115
+          const double km = kc * ck[1];     // :119
+          xm[q] = xm[q] + km * ck[0];       // :130
+          const double kb = ck[2] * km;     // :136
+#pragma unroll
+          for (int c = 0; c < 2 * NC; ++c) x[q][c] = __builtin_fma(-kb, y[c], x[q][c]);  // :141
+        }
       }
     }
-    if (live) {
-      if (FUSED) {  // posterior members out (assimilation.py:168)
 #pragma unroll
-        for (int c = 0; c < 2 * NC; ++c) x[c] += xm;
+    for (int q = 0; q < RPL; ++q) {
+      if (live[q]) {
+        if (FUSED) {  // posterior members out (assimilation.py:168)
+#pragma unroll
+          for (int c = 0; c < 2 * NC; ++c) x[q][c] += xm[q];
+        }
+        store_row<L, NC, VEC>(a.Xout + (size_t)row[q] * M, M, j, x[q]);
+        if (!FUSED && j == 0) a.xout[row[q]] = xm[q];
       }
-      store_row<L, NC, VEC>(a.Xout + (size_t)row * M, M, j, x);
-      if (!FUSED && j == 0) a.xout[row] = xm;
     }
   }
 }
@@ -205,12 +222,13 @@ template <int NC>
 hipError_t gc_launch(const GcSweepArgs& a, hipStream_t s) {
   const bool vec = (a.M % 2 == 0) && (a.ye_stride % 2 == 0) && aligned16(a.Xin) && aligned16(a.Xout) && aligned16(a.Ye);
   const dim3 grid((unsigned)a.nblk), block(256);
+  constexpr int RPL = (NC <= 13) ? 2 : 1;  // two rows per quad while they fit the register file at 2+ waves per SIMD
   if (a.fused_members) {
-    if (vec) hipLaunchKernelGGL((k_sweep_gc<NC, true, true>), grid, block, 0, s, a);
-    else hipLaunchKernelGGL((k_sweep_gc<NC, false, true>), grid, block, 0, s, a);
+    if (vec) hipLaunchKernelGGL((k_sweep_gc<NC, true, true, RPL>), grid, block, 0, s, a);
+    else hipLaunchKernelGGL((k_sweep_gc<NC, false, true, RPL>), grid, block, 0, s, a);
   } else {
-    if (vec) hipLaunchKernelGGL((k_sweep_gc<NC, true, false>), grid, block, 0, s, a);
-    else hipLaunchKernelGGL((k_sweep_gc<NC, false, false>), grid, block, 0, s, a);
+    if (vec) hipLaunchKernelGGL((k_sweep_gc<NC, true, false, RPL>), grid, block, 0, s, a);
+    else hipLaunchKernelGGL((k_sweep_gc<NC, false, false, RPL>), grid, block, 0, s, a);
   }
   return hipGetLastError();
 }
