@@ -130,15 +130,28 @@ __global__ __launch_bounds__(kGT) void k_pipe_gram(const PipeArgs a) {
   // Cycle stamps for tools/gram_stamps*.py exist only in diagnostic builds (make STAMPS=1): an s_memtime
   // anywhere in a loop makes the compiler wait for ALL outstanding LDS traffic (lgkmcnt(0)) wherever it
   // waits at all, because scalar-memory results may return out of order with LDS results.
-#ifdef EFA_PIPE_STAMPS
+#ifdef EFA_PIPE_BLOCKTIME  /* make EXTRA=-DEFA_PIPE_BLOCKTIME: three stamps per block, none inside a loop */
+#define EFA_BLOCKSTAMP(cond, slot)                                                                  \
+  do {                                                                                              \
+    if (a.dbg != nullptr && (cond)) a.dbg[(size_t)own0 * 8 + (slot)] = __builtin_amdgcn_s_memtime(); \
+  } while (0)
+#else
+#define EFA_BLOCKSTAMP(cond, slot) \
+  do {                              \
+  } while (0)
+#endif
+#if defined(EFA_PIPE_STAMPS) || defined(EFA_PIPE_BLOCKTIME)
 #define EFA_EXP(bit) ((a.debug & (bit)) != 0)  /* timing experiments of tools/gram_exp*.py: results are wrong */
+#else
+#define EFA_EXP(bit) false
+#endif
+#ifdef EFA_PIPE_STAMPS
 #define EFA_GSTAMP(cond, kidx, slot)                                                                          \
   do {                                                                                                          \
     if (a.dbg != nullptr && (!(a.debug & 128) || (slot) == 0 || (slot) == 7) && (cond))                         \
       a.dbg[(size_t)(kidx) * 8 + (slot)] = __builtin_amdgcn_s_memtime();                                        \
   } while (0)
 #else
-#define EFA_EXP(bit) false
 #define EFA_GSTAMP(cond, kidx, slot) \
   do {                                \
   } while (0)
@@ -274,6 +287,7 @@ __global__ __launch_bounds__(kGT) void k_pipe_gram(const PipeArgs a) {
       }
     };
     follow(0, (own0 < P) ? own0 : P);
+    EFA_BLOCKSTAMP(lane == 0 && leads, 3);
     if (leads && !failed) {
       __syncthreads();  // B1: the vector waves have parked their rows in the tile
       form_gram();
@@ -302,6 +316,7 @@ __global__ __launch_bounds__(kGT) void k_pipe_gram(const PipeArgs a) {
         if (lane == 0) g_ctl_set(&ctl[cFwd], (int)f);
         EFA_GSTAMP(lane == 0, f, 7);
       }
+      EFA_BLOCKSTAMP(lane == 0, 2);
       __syncthreads();  // B3: done with the pivot's records
       barriers_left = 0;
       if (!failed) follow(own1, P);
@@ -359,6 +374,7 @@ __global__ __launch_bounds__(kGT) void k_pipe_gram(const PipeArgs a) {
       constexpr bool seg = false;
 #endif
       u64 segsum[4] = {0, 0, 0, 0}, tprev = 0;
+      EFA_BLOCKSTAMP(lane == 0, 0);
       for (int kk = 0; kk < nb; ++kk) {
         u64 T0 = 0, T1 = 0, T2 = 0, T3 = 0;
         if (seg) T0 = __builtin_amdgcn_s_memtime();
@@ -479,6 +495,7 @@ __global__ __launch_bounds__(kGT) void k_pipe_gram(const PipeArgs a) {
       if (seg && lane == 0 && nb == kRowsWG) {
         for (int i = 0; i < 4; ++i) a.dbg[(size_t)(own0 + i) * 8 + 5] = segsum[i];
       }
+      EFA_BLOCKSTAMP(lane == 0, 1);
       pm[kRowsWG + lane] = xmv;  // obs-space means of all 64 rows after the block, back to the vector waves
       __syncthreads();  // B3
       if (!bailed && g_ctl(&ctl[cBail]) == 0 && is_ob) {
