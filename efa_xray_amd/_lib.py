@@ -179,6 +179,14 @@ class DeviceArray(object):
         _check(self.ctx.lib, self.ctx.lib.efa_memcpy_d2h(self.ctx.handle, out.ctypes.data, self.ptr, self.nbytes))
         return out
 
+    def download_rows(self, r0, r1):
+        """Rows [r0, r1) of a 2-D (or 1-D) array, without copying the rest."""
+        width = int(np.prod(self.shape[1:], dtype=np.int64)) if len(self.shape) > 1 else 1
+        out = np.empty((r1 - r0,) + self.shape[1:], dtype=np.float64)
+        src = ctypes.c_void_p(self.ptr.value + r0 * width * 8)
+        _check(self.ctx.lib, self.ctx.lib.efa_memcpy_d2h(self.ctx.handle, out.ctypes.data, src, out.nbytes))
+        return out
+
     def free(self):
         if self.ptr is not None and self.ptr.value and self.ctx.handle is not None:
             self.ctx.lib.efa_free(self.ctx.handle, self.ptr)

@@ -430,14 +430,16 @@ __global__ __launch_bounds__(kGT) void k_pipe_gram(const PipeArgs a) {
           asm volatile("" ::"v"(kb));
           T1 = __builtin_amdgcn_s_memtime();
         }
-        s_gk[kk * kRowsWG + lane] = make_double2(g, kb);
+        if (!EFA_EXP(16384)) s_gk[kk * kRowsWG + lane] = make_double2(g, kb);
         if (lane == 0) {
           double2* sc = reinterpret_cast<double2*>(s_sc + (size_t)kk * 4);
-          sc[0] = make_double2(innov, rden);
-          sc[1] = make_double2(beta, act ? 1.0 : 0.0);
+          if (!EFA_EXP(16384)) {
+            sc[0] = make_double2(innov, rden);
+            sc[1] = make_double2(beta, act ? 1.0 : 0.0);
+          }
           g_ctl_set(&ctl[cSReady], kk + 1);
         }
-        if (lane == kk) {  // this ob's diagnostics stay in its lane
+        if (lane == kk && !EFA_EXP(8192)) {  // this ob's diagnostics stay in its lane
           o_pm = xmk;                                  // :66
           o_pv = __builtin_fma(Gkk, invM, -mu2);       // np.var, ddof = 0 (:69, :70)
           o_in = innov;
@@ -456,7 +458,7 @@ __global__ __launch_bounds__(kGT) void k_pipe_gram(const PipeArgs a) {
           const double gi = rl(g, kk + 1), ai = rl(kb, kk + 1);
           const double gnew = __builtin_fma(-ai, t, __builtin_fma(-kb, gi, g1));
           if (kk + 2 < nb) {
-            if (kk >= 1 && __builtin_amdgcn_readfirstlane(f_early) < kk + 2) {
+            if (kk >= 1 && __builtin_amdgcn_readfirstlane(f_early) < kk + 2 && !EFA_EXP(4096)) {
               const int* flag = &ctl[cHProg + (kk & 1)];
               for (;;) {
                 const int f = g_ctl_lane(flag);

@@ -411,6 +411,65 @@ def test_sweep_and_transform_paths_agree_at_scale():
     assert_parity(d["post_var"], rd["post_var"], "post_var")
 
 
+def test_headline_size_properties():
+    """BASELINE.json's full size (1e7 state rows x 100 members x 1e4 obs, float64, loc=None): properties that
+    do not need an oracle run of that size.
+      - the one-pass transform and the per-batch sweeps (157 read+write passes) give the same posterior;
+      - no row's ensemble variance grows (each serial EnSRF update shrinks it);
+      - the row observed by the LAST ob reproduces that ob's post_mean / post_var;
+      - a cycle in which no ob is assimilated returns mean + (prior - mean), as the reference does
+        (assimilation.py:146-147,168), i.e. the prior to rounding."""
+    ctx = _ctx()
+    rows, M, P = 10_000_000, 100, 10_000
+    rng = np.random.default_rng(11)
+    X = ctx.empty((rows, M))
+    ctx.fill_synthetic(rows, 0, M, 4321, 3.0, X)
+    pick = np.sort(rng.choice(rows, P, replace=False)).astype(np.int64)
+    HX = ctx.empty((P, M))
+    ctx.forward_stencil(rows, 0, M, X, pick[:, None], np.ones((P, 1)), HX)
+    hx = HX.download()
+    val = hx.mean(axis=1) + rng.standard_normal(P)
+    err = np.ones(P)
+    blocks = [(int(r0), int(r0) + 4096) for r0 in rng.choice(rows - 4096, 12, replace=False)] + [(rows - 4096, rows)]
+    post = ctx.empty((rows, M))
+    got = {}
+    try:
+        for path in (2, 1):
+            ctx.set_option("path", path)
+            ym = ctx.empty((P,))
+            Yp = ctx.to_device(hx)
+            ctx.form_perts(P, M, Yp, ym, Yp)
+            d = ctx.obs_phase(M, P, ym, Yp, val, err, np.ones(P, dtype=bool))
+            ctx.state_cycle(rows, M, X, post)
+            assert ctx.last_timing()["path"] == path
+            got[path] = ([post.download_rows(a, b) for a, b in blocks], post.download_rows(int(pick[-1]), int(pick[-1]) + 1)[0], d)
+        for (a, b), pa, pb, in zip(blocks, got[2][0], got[1][0]):
+            prior = X.download_rows(a, b)
+            assert np.isfinite(pa).all()
+            assert np.abs(pa - pb).max() <= 1e-10 * np.abs(pb).max(), "transform vs sweep rows %d..%d" % (a, b)
+            assert (pa.var(axis=1) <= prior.var(axis=1) * (1.0 + 1e-9)).all(), "variance grew in rows %d..%d" % (a, b)
+        for path in (1, 2):
+            last, d = got[path][1], got[path][2]
+            assert abs(last.mean() - d["post_mean"][-1]) <= 1e-10 * max(1.0, abs(d["post_mean"][-1]))
+            assert abs(last.var() - d["post_var"][-1]) <= 1e-9 * max(1.0, d["post_var"][-1])
+        assert_parity(got[2][2]["prior_var"], got[1][2]["prior_var"], "prior_var, transform vs sweep trajectory")
+        # nothing assimilated: the posterior members are the prior members (re-centred and restored)
+        ctx.set_option("path", 0)
+        ym = ctx.empty((P,))
+        Yp = ctx.to_device(hx)
+        ctx.form_perts(P, M, Yp, ym, Yp)
+        d0 = ctx.obs_phase(M, P, ym, Yp, val, err, np.zeros(P, dtype=bool))
+        ctx.state_cycle(rows, M, X, post)
+        assert not d0["assimilated"].any()
+        for a, b in blocks[:4]:
+            pr = X.download_rows(a, b)
+            assert np.abs(post.download_rows(a, b) - pr).max() <= 4e-15 * np.abs(pr).max()
+    finally:
+        ctx.set_option("path", 0)
+        post.free()
+        X.free()
+
+
 def test_helper_kernels_vs_oracle():
     ctx = _ctx()
     rng = np.random.default_rng(8)

@@ -21,9 +21,10 @@ out = np.zeros((P, 8), dtype=np.uint64)
 _lib._check(ctx.lib, ctx.lib.efa_memcpy_d2h(ctx.handle, out.ctypes.data, ctypes.c_void_p(addr), out.nbytes))
 t = out.astype(np.int64)
 nb = P // 64
-piv = [t[64 * b, 1] - t[64 * b, 0] for b in range(1, nb)]
-blk = [t[64 * b, 2] - t[64 * b, 0] for b in range(1, nb)]
-pre = [t[64 * b, 0] - t[64 * b, 3] for b in range(1, nb)]
+first = 0 if nb == 1 else 1
+piv = [t[64 * b, 1] - t[64 * b, 0] for b in range(first, nb)]
+blk = [t[64 * b, 2] - t[64 * b, 0] for b in range(first, nb)]
+pre = [t[64 * b, 0] - t[64 * b, 3] for b in range(first, nb)]
 print("bits", bits, "kind", ctx.get_option("phase_a_kind"))
 print("pivot loop (64 steps):               median %7.0f cycles = %5.0f per step" % (np.median(piv), np.median(piv) / 64))
 print("pivot start -> last record forwarded: median %7.0f cycles = %5.0f per step" % (np.median(blk), np.median(blk) / 64))
