@@ -298,6 +298,7 @@ __global__ __launch_bounds__(kGT) void k_pipe_gram(const PipeArgs a) {
         }
       }
       __syncthreads();  // B2: G and the taper corner are complete
+      if (EFA_EXP(65536)) return;  // TIMING EXPERIMENT (single workgroup only): the pivot wave alone
       barriers_left = 1;
       for (long f = own0; f < own1; ++f) {
         if (!wait2_gt(&ctl[cReady], (int)f, &ctl[cSReady], (int)(f - own0), true)) {
@@ -341,6 +342,7 @@ __global__ __launch_bounds__(kGT) void k_pipe_gram(const PipeArgs a) {
     __syncthreads();  // B1
     form_gram();
     __syncthreads();  // B2
+    if (EFA_EXP(65536) && wave != kVW) return;
     if (wave == kVW) {
       // ---------------- pivot wave: lane j <-> row j of the workgroup ----------------
       // The loop below is the serial chain of the whole filter, and one wave issues in order: every
@@ -368,17 +370,27 @@ __global__ __launch_bounds__(kGT) void k_pipe_gram(const PipeArgs a) {
       const bool gc = a.loc_mode != 0;
       const double* twp = gc ? tw_s + lane : pv + lane;  // always a valid address: the load is unconditional
       double twn = twp[0];
-#ifdef EFA_PIPE_STAMPS
-      const bool seg = (a.debug & 256) != 0 && a.dbg != nullptr;
-#else
-      constexpr bool seg = false;
-#endif
-      u64 segsum[4] = {0, 0, 0, 0}, tprev = 0;
-      EFA_BLOCKSTAMP(lane == 0, 0);
-      for (int kk = 0; kk < nb; ++kk) {
-        u64 T0 = 0, T1 = 0, T2 = 0, T3 = 0;
-        if (seg) T0 = __builtin_amdgcn_s_memtime();
-        EFA_GSTAMP(lane == 0, own0 + kk, 0);
+      // slow path of the hand-over (the helper is late): poll flag and row together
+      auto wait_row = [&](int kk, double& r2) {
+        const int* flag = &ctl[cHProg + (kk & 1)];
+        for (;;) {
+          const int f = g_ctl_lane(flag);
+          r2 = G_s[(kk + 2) * kRowsWG + lane];
+          if (__builtin_amdgcn_readfirstlane(f) >= kk + 2) return true;
+          if ((++polls & 15) == 0) {
+            budget -= 16;
+            if (g_ctl(&ctl[cBail]) != 0) return false;
+            if (budget <= 0) {
+              if (lane == 0) give_up();
+              return false;
+            }
+          }
+        }
+      };
+      // One step of the recurrence.  has1 / has2: rows kk+1 / kk+2 exist; poll: row kk+2 comes from a
+      // helper (kk >= 1).  The block loop below calls it with constants, so the steady-state body is
+      // straight-line code: a taken branch costs this wave more than a dozen arithmetic instructions.
+      auto pivot_step = [&](const int kk, const bool has1, const bool has2, const bool poll) {
         const double valk = valn, errk = errn, sqk = sqn, twk = twn;
         {
           const int kn = (kk + 1 < kRowsWG) ? kk + 1 : kk;
@@ -388,20 +400,9 @@ __global__ __launch_bounds__(kGT) void k_pipe_gram(const PipeArgs a) {
           twn = twp[gc ? kn * kRowsWG : 0];
         }
         const bool act = ((asm_mask >> kk) & 1) != 0;
-        if (((__ballot(!(g > thr)) >> kk) & 1) != 0 && !EFA_EXP(0x70)) {  // the downdate may have cancelled: leave it to efa_pipeline.hip
+        if (((__ballot(!(g > thr)) >> kk) & 1) != 0 && !EFA_EXP(0x70)) {  // the downdate may have cancelled
           if (lane == 0) give_up();
-          bailed = true;
-          break;
-        }
-        if (EFA_EXP(2048)) {  // TIMING EXPERIMENT: no arithmetic on the chain at all, only the protocol
-          s_gk[kk * kRowsWG + lane] = make_double2(g, 0.0);
-          if (lane == 0) {
-            double2* sc = reinterpret_cast<double2*>(s_sc + (size_t)kk * 4);
-            sc[0] = make_double2(0.0, 1.0);
-            sc[1] = make_double2(0.5, 1.0);
-            g_ctl_set(&ctl[cSReady], kk + 1);
-          }
-          continue;
+          return false;
         }
         const double Gkk = rl(g, kk), muk = rl(mu, kk), xmk = rl(xmv, kk);
         const double mu2 = muk * muk;
@@ -418,28 +419,26 @@ __global__ __launch_bounds__(kGT) void k_pipe_gram(const PipeArgs a) {
         const double beta0 = __builtin_fma(r0, __builtin_fma(eb, eb, eb), r0);
         const double beta = __builtin_fma(-((beta0 * beta0) * sq0), d, beta0);  // 1 / (1 + sqrt(err / kdenom))  (:135)
         double kc = g * rM1;                                          // :95
-        if (gc) kc = twk * kc;                                        // :115
+        kc = (gc ? twk : 1.0) * kc;                                   // :115
         const double km = act ? kc * rden : 0.0;                      // :119
         const double kb = beta * km;                                  // :136
         const double innov = valk - xmk;                              // :85
         // row kk+2 from its helper, read speculatively here (the helper had the whole gain chain above to
         // hand it over; the round trip overlaps the publication below): flag first, then the row
-        const int f_early = g_ctl_lane(&ctl[cHProg + (kk & 1)]);
-        double r2 = G_s[((kk + 2 < kRowsWG) ? kk + 2 : 0) * kRowsWG + lane];
-        if (seg) {
-          asm volatile("" ::"v"(kb));
-          T1 = __builtin_amdgcn_s_memtime();
+        int f_early = 0;
+        double r2 = 0.0;
+        if (has2) {
+          f_early = poll ? g_ctl_lane(&ctl[cHProg + (kk & 1)]) : 0;
+          r2 = G_s[(kk + 2) * kRowsWG + lane];
         }
-        if (!EFA_EXP(16384)) s_gk[kk * kRowsWG + lane] = make_double2(g, kb);
+        s_gk[kk * kRowsWG + lane] = make_double2(g, kb);
         if (lane == 0) {
           double2* sc = reinterpret_cast<double2*>(s_sc + (size_t)kk * 4);
-          if (!EFA_EXP(16384)) {
-            sc[0] = make_double2(innov, rden);
-            sc[1] = make_double2(beta, act ? 1.0 : 0.0);
-          }
+          sc[0] = make_double2(innov, rden);
+          sc[1] = make_double2(beta, act ? 1.0 : 0.0);
           g_ctl_set(&ctl[cSReady], kk + 1);
         }
-        if (lane == kk && !EFA_EXP(8192)) {  // this ob's diagnostics stay in its lane
+        if (lane == kk) {  // this ob's diagnostics stay in its lane
           o_pm = xmk;                                  // :66
           o_pv = __builtin_fma(Gkk, invM, -mu2);       // np.var, ddof = 0 (:69, :70)
           o_in = innov;
@@ -447,55 +446,35 @@ __global__ __launch_bounds__(kGT) void k_pipe_gram(const PipeArgs a) {
           o_be = beta;
           o_km = km;
         }
-        EFA_GSTAMP(lane == 0, own0 + kk, 1);
-        if (seg) T2 = __builtin_amdgcn_s_memtime();
         xmv = xmv + km * innov;                                       // :130
         mu = __builtin_fma(-kb, muk, mu);
-        if (kk + 1 < nb) {
+        if (has1) {
           // g1 = row kk+1 through step kk-1; row kk+2 through step kk-1 comes from its helper (handed
-          // over through G_s during the helper's step kk-1, read speculatively before the publication above)
+          // over through G_s during the helper's step kk-1)
           const double t = __builtin_fma(-kb, Gkk, g);
           const double gi = rl(g, kk + 1), ai = rl(kb, kk + 1);
           const double gnew = __builtin_fma(-ai, t, __builtin_fma(-kb, gi, g1));
-          if (kk + 2 < nb) {
-            if (kk >= 1 && __builtin_amdgcn_readfirstlane(f_early) < kk + 2 && !EFA_EXP(4096)) {
-              const int* flag = &ctl[cHProg + (kk & 1)];
-              for (;;) {
-                const int f = g_ctl_lane(flag);
-                r2 = G_s[(kk + 2) * kRowsWG + lane];
-                if (__builtin_amdgcn_readfirstlane(f) >= kk + 2) break;
-                if ((++polls & 15) == 0) {
-                  budget -= 16;
-                  if (g_ctl(&ctl[cBail]) != 0) bailed = true;
-                  else if (budget <= 0) {
-                    if (lane == 0) give_up();
-                    bailed = true;
-                  }
-                  if (bailed) break;
-                }
-              }
-              if (bailed) break;
+          if (has2) {
+            if (poll && __builtin_amdgcn_readfirstlane(f_early) < kk + 2) {
+              if (!wait_row(kk, r2)) return false;
             }
             const double gi2 = rl(g, kk + 2), ai2 = rl(kb, kk + 2);
             g1 = __builtin_fma(-ai2, t, __builtin_fma(-kb, gi2, r2));
           }
           g = gnew;
-          EFA_GSTAMP(lane == 0, own0 + kk, 2);
         }
-        if (seg) {
-          asm volatile("" ::"v"(g), "v"(g1));
-          T3 = __builtin_amdgcn_s_memtime();
-          if (kk >= 4 && kk < 60) {
-            segsum[0] += T1 - T0;
-            segsum[1] += T2 - T1;
-            segsum[2] += T3 - T2;
-            segsum[3] += T0 - tprev;
-          }
-          tprev = T3;
+        return true;
+      };
+      EFA_BLOCKSTAMP(lane == 0, 0);
+      {
+        int kk = 0;
+        bool ok = true;
+        if (nb >= 3) {
+          ok = pivot_step(0, true, true, false);
+          for (kk = 1; ok && kk < nb - 2; ++kk) ok = pivot_step(kk, true, true, true);  // steady state
         }
-      }
-      if (seg && lane == 0 && nb == kRowsWG) {
-        for (int i = 0; i < 4; ++i) a.dbg[(size_t)(own0 + i) * 8 + 5] = segsum[i];
+        for (; ok && kk < nb; ++kk) ok = pivot_step(kk, kk + 1 < nb, kk + 2 < nb, kk >= 1);
+        bailed = !ok;
       }
       EFA_BLOCKSTAMP(lane == 0, 1);
       pm[kRowsWG + lane] = xmv;  // obs-space means of all 64 rows after the block, back to the vector waves
@@ -659,6 +638,7 @@ __global__ __launch_bounds__(kGT) void k_pipe_gram(const PipeArgs a) {
 #pragma unroll
         for (int v = 0; v < 4; ++v) xt[J][v] = Yt[(size_t)(16 * v + 4 * lr + wave) * SP + 16 * J + lc];
       __syncthreads();  // B2: G complete; the tile region now belongs to the pivot wave's records
+      if (EFA_EXP(65536)) return;
       barriers_left = 1;
       auto publish_row = [&](int r) {  // block row r (held by this wave: (r & 3) == wave) IS ye of ob own0 + r
         double* slot = ring + (size_t)((own0 + r) % kRingG) * TS;
