@@ -264,6 +264,11 @@ def main():
                          "launch_fp64_TFLOPs": flops_launch / (avg_launch_ms * 1e-3) / 1e12,
                          "launch_fp64_frac": flops_launch / (avg_launch_ms * 1e-3) / 1e12 / FP64_PEAK_TFLOPS},
         }
+        if loc:
+            # a localised sweep touches only the rows inside each ob's support: the dense flop count does not apply
+            out["roofline"]["launch_fp64_TFLOPs"] = None
+            out["roofline"]["launch_fp64_frac"] = None
+            out["roofline"]["kernel"] = "k_sweep_gc"
         if world == 1 and not args.no_cpu_baseline:
             n_cpu_rows = min(args.cpu_rows, rows)
             n_cpu_obs = min(args.cpu_obs + 1, P)
