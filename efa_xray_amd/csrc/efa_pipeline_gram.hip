@@ -366,10 +366,14 @@ __global__ __launch_bounds__(kGT) void k_pipe_gram(const PipeArgs a) {
       double g1 = G_s[kRowsWG + lane];  // row 1
       // per-ob constants (and the taper row) are fetched one step ahead: an LDS round trip at the top of a
       // step would sit on the chain
-      double valn = pv[0], errn = pv[kRowsWG], sqn = pv[2 * kRowsWG];
+      struct Pre {
+        double val, err, sq, tw;
+      };
       const bool gc = a.loc_mode != 0;
       const double* twp = gc ? tw_s + lane : pv + lane;  // always a valid address: the load is unconditional
-      double twn = twp[0];
+      // two register sets used alternately (the loop is unrolled by two): with one set the compiler copies
+      // "next" into "current" at the back edge and, for that, drains the whole LDS queue every step
+      Pre pa{pv[0], pv[kRowsWG], pv[2 * kRowsWG], twp[0]}, pb{0.0, 1.0, 1.0, 1.0};
       // slow path of the hand-over (the helper is late): poll flag and row together
       auto wait_row = [&](int kk, double& r2) {
         const int* flag = &ctl[cHProg + (kk & 1)];
@@ -390,17 +394,17 @@ __global__ __launch_bounds__(kGT) void k_pipe_gram(const PipeArgs a) {
       // One step of the recurrence.  has1 / has2: rows kk+1 / kk+2 exist; poll: row kk+2 comes from a
       // helper (kk >= 1).  The block loop below calls it with constants, so the steady-state body is
       // straight-line code: a taken branch costs this wave more than a dozen arithmetic instructions.
-      auto pivot_step = [&](const int kk, const bool has1, const bool has2, const bool poll) {
-        const double valk = valn, errk = errn, sqk = sqn, twk = twn;
+      auto pivot_step = [&](const int kk, const bool has1, const bool has2, const bool poll, const Pre& cur, Pre& nxt) {
+        const double valk = cur.val, errk = cur.err, sqk = cur.sq, twk = cur.tw;
         {
           const int kn = (kk + 1 < kRowsWG) ? kk + 1 : kk;
-          valn = pv[kn];
-          errn = pv[kRowsWG + kn];
-          sqn = pv[2 * kRowsWG + kn];
-          twn = twp[gc ? kn * kRowsWG : 0];
+          nxt.val = pv[kn];
+          nxt.err = pv[kRowsWG + kn];
+          nxt.sq = pv[2 * kRowsWG + kn];
+          nxt.tw = twp[gc ? kn * kRowsWG : 0];
         }
         const bool act = ((asm_mask >> kk) & 1) != 0;
-        if (((__ballot(!(g > thr)) >> kk) & 1) != 0 && !EFA_EXP(0x70)) {  // the downdate may have cancelled
+        if (__builtin_expect(((__ballot(!(g > thr)) >> kk) & 1) != 0 && !EFA_EXP(0x70), 0)) {  // the downdate may have cancelled
           if (lane == 0) give_up();
           return false;
         }
@@ -455,7 +459,7 @@ __global__ __launch_bounds__(kGT) void k_pipe_gram(const PipeArgs a) {
           const double gi = rl(g, kk + 1), ai = rl(kb, kk + 1);
           const double gnew = __builtin_fma(-ai, t, __builtin_fma(-kb, gi, g1));
           if (has2) {
-            if (poll && __builtin_amdgcn_readfirstlane(f_early) < kk + 2) {
+            if (__builtin_expect(poll && __builtin_amdgcn_readfirstlane(f_early) < kk + 2, 0)) {
               if (!wait_row(kk, r2)) return false;
             }
             const double gi2 = rl(g, kk + 2), ai2 = rl(kb, kk + 2);
@@ -469,11 +473,18 @@ __global__ __launch_bounds__(kGT) void k_pipe_gram(const PipeArgs a) {
       {
         int kk = 0;
         bool ok = true;
-        if (nb >= 3) {
-          ok = pivot_step(0, true, true, false);
-          for (kk = 1; ok && kk < nb - 2; ++kk) ok = pivot_step(kk, true, true, true);  // steady state
+        if (nb >= 4) {
+          ok = pivot_step(0, true, true, false, pa, pb);
+          for (kk = 1; ok && kk + 1 < nb - 2; kk += 2) {  // steady state, two steps per trip
+            ok = pivot_step(kk, true, true, true, pb, pa);
+            if (ok) ok = pivot_step(kk + 1, true, true, true, pa, pb);
+          }
         }
-        for (; ok && kk < nb; ++kk) ok = pivot_step(kk, kk + 1 < nb, kk + 2 < nb, kk >= 1);
+        // the rest one by one (kk odd: the current constants are in pb)
+        for (; ok && kk < nb; ++kk) {
+          if (kk & 1) ok = pivot_step(kk, kk + 1 < nb, kk + 2 < nb, kk >= 1, pb, pa);
+          else ok = pivot_step(kk, kk + 1 < nb, kk + 2 < nb, kk >= 1, pa, pb);
+        }
         bailed = !ok;
       }
       EFA_BLOCKSTAMP(lane == 0, 1);
