@@ -30,26 +30,64 @@ class Assimilation(object):
     def _context(self):
         return _lib.get_context(self.device)
 
-    def _inflation_factor(self):
-        """Only the constant-float form of assimilation.py:62-69 is supported;
-        it is applied to the perturbations on the GPU and -- unlike the
-        reference, which overwrites the caller's state (assimilation.py:67) --
-        leaves `self.prior` untouched."""
-        if self.inflation is None:
-            return 1.0
-        if isinstance(self.inflation, (float, np.floating)):
-            return float(self.inflation)
-        raise NotImplementedError(
-            "inflation=%r: only None or a float is supported (dict / file inflation of "
-            "assimilation.py:71-114 needs xarray broadcasting and is out of scope)" % (self.inflation,))
+    _DIM_AXIS = {"validtime": 0, "y": 1, "x": 2}
 
     def inflate_state(self):
-        """Kept for API compatibility (assimilation.py:52-118): records that the
-        constant factor will be applied when the perturbations are formed."""
+        """Inflate the prior as specified by `inflation` (assimilation.py:52-118).
+
+        As in the reference this is a separate step the caller invokes -- `update()` never calls
+        it (ensrf.py:33-151) -- and it changes `self.prior`: a float scales the ensemble
+        perturbations of every variable (assimilation.py:62-69); a dict maps variable names to
+        float factors (:103-113) or the dimension names 'validtime' / 'y' / 'x' to arrays of
+        per-index factors that are broadcast over the other dimensions (:82-100).  The file
+        form (:71-79, an xarray/netCDF dataset of factors) is not supported."""
         if self.is_inflated:
             print("State already inflated.  Skipping additional inflation.")
             return
-        self._inflation_factor()
+        prior = self.prior
+
+        def scale_var(name, factor):
+            v = prior.variables[name]
+            mean = v.mean(axis=-1, keepdims=True)
+            if self.verbose:
+                print(name, "BEFORE stdev:", np.mean(np.std(v, axis=-1), axis=None))
+            prior.variables[name] = np.ascontiguousarray((v - mean) * factor + mean)
+            if self.verbose:
+                print(name, "AFTER stdev:", np.mean(np.std(prior.variables[name], axis=-1), axis=None))
+
+        if isinstance(self.inflation, (float, np.floating)):
+            if self.verbose:
+                print("Inflating all variables by factor: {:3.2f}".format(self.inflation))
+            for name in prior.vars():
+                scale_var(name, float(self.inflation))
+        elif isinstance(self.inflation, str):
+            raise NotImplementedError("inflation from a file (assimilation.py:71-79) needs an xarray/netCDF dataset "
+                                      "of factors; pass a float or a dict instead")
+        else:
+            for k, v in self.inflation.items():  # a dictionary, as in the reference
+                if k in ("validtime", "lat", "lon", "x", "y"):
+                    if k not in self._DIM_AXIS:
+                        raise NotImplementedError("inflation along %r: lat/lon are 2-D coordinates here, "
+                                                  "use 'y' / 'x'" % k)
+                    v = np.asarray(v, dtype=np.float64)
+                    axis = self._DIM_AXIS[k]
+                    assert v.shape[0] == prior._first().shape[axis]  # assimilation.py:88-89
+                    if self.verbose:
+                        print("Inflating all variables along {:s} dimension".format(k))
+                    # the reference rebinds self.prior to a new object here (assimilation.py:96)
+                    prior = self.prior = deepcopy(prior)
+                    shape = [1, 1, 1, 1]
+                    shape[axis] = v.shape[0]
+                    for name in prior.vars():
+                        scale_var(name, v.reshape(shape))
+                else:
+                    assert isinstance(v, (float, np.floating))  # assimilation.py:106
+                    if k not in prior.variables:
+                        print("Unable to find variable {:s} to inflate.  Skipping...".format(k))
+                        continue
+                    if self.verbose:
+                        print("Inflating variable {:s} by factor: {:3.2f}".format(k, v))
+                    scale_var(k, float(v))
         self.is_inflated = True
 
     def compute_ob_estimates(self):
@@ -70,21 +108,19 @@ class Assimilation(object):
         ctx = self._context()
         d = ctx.to_device(HX)
         m = ctx.empty((P,))
-        ctx.form_perts(P, M, d, m, d, scale=self._inflation_factor())
+        ctx.form_perts(P, M, d, m, d)
         return m.download(), d.download()
 
     def format_prior_state(self):
         """Augmented (xbm, Xbp): state rows then one row per ob
         (assimilation.py:120-154)."""
-        if self.inflation is not None:
-            self.inflate_state()
         obmeans, obperts = self.compute_ob_priors()
         X = np.ascontiguousarray(self.prior.to_vect(), dtype=np.float64)
         N, M = X.shape
         ctx = self._context()
         d = ctx.to_device(X)
         m = ctx.empty((N,))
-        ctx.form_perts(N, M, d, m, d, scale=self._inflation_factor())
+        ctx.form_perts(N, M, d, m, d)
         xbm = np.hstack((m.download(), obmeans))
         Xbp = np.vstack((d.download(), obperts))
         return xbm, Xbp

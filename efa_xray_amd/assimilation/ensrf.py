@@ -81,9 +81,6 @@ class EnSRF(Assimilation):
         M = prior.nmems()
         loc_mode = self._loc_mode()
         P, value, error, assim, lat, lon, hw = self._ob_arrays(loc_mode)
-        scale = self._inflation_factor() if self.inflation is not None else 1.0
-        if self.inflation is not None:
-            self.inflate_state()
 
         # forward operator, once per ob from the prior (assimilation.py:45-48)
         if self.verbose:
@@ -99,7 +96,7 @@ class EnSRF(Assimilation):
         ym = ctx.empty((max(P, 1),))
         Yp = ctx.to_device(HX) if P else ctx.empty((1, M))
         if P:
-            ctx.form_perts(P, M, Yp, ym, Yp, scale=scale)      # assimilation.py:46-48
+            ctx.form_perts(P, M, Yp, ym, Yp)                   # assimilation.py:46-48
 
         grid_lat = grid_lon = None
         n_lead = 1
@@ -110,13 +107,7 @@ class EnSRF(Assimilation):
         if self.verbose:
             print("Beginning observation loop")
         diag = ctx.obs_phase(M, P, ym, Yp, value, error, assim, loc_mode, lat, lon, hw)
-        if scale == 1.0:
-            ctx.state_cycle(N, M, X, X, grid_lat, grid_lon, n_lead)
-        else:
-            xm = ctx.empty((N,))
-            ctx.form_perts(N, M, X, xm, X, scale=scale)
-            ctx.state_phase(N, M, xm, X, xm, X, grid_lat, grid_lon, n_lead)
-            ctx.posterior(N, M, xm, X, X)
+        ctx.state_cycle(N, M, X, X, grid_lat, grid_lon, n_lead)
         self.last_timing = ctx.last_timing()
         post = X.download()
 
