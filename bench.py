@@ -264,6 +264,12 @@ def main():
                          "launch_fp64_TFLOPs": flops_launch / (avg_launch_ms * 1e-3) / 1e12,
                          "launch_fp64_frac": flops_launch / (avg_launch_ms * 1e-3) / 1e12 / FP64_PEAK_TFLOPS},
         }
+        # Phase A (the serial chain) is the longer of the two launches at the headline size: it moves ~95 MB
+        # and is bound by the step latency of ONE workgroup, so neither roofline applies; reported for scale
+        kind = ctx.get_option("phase_a_kind")
+        out["phase_a"] = {"kernel": {1: "k_pipe", 2: "k_diag+k_sweep", 3: "k_pipe_gram"}.get(kind, "?"),
+                          "bound": "latency of the serial per-observation chain (one workgroup leads at a time)",
+                          "ms": obs_ms / args.steps, "us_per_ob": 1e3 * obs_ms / args.steps / max(P, 1)}
         if loc:
             # a localised sweep touches only the rows inside each ob's support: the dense flop count does not apply
             out["roofline"]["launch_fp64_TFLOPs"] = None
