@@ -403,6 +403,15 @@ __global__ __launch_bounds__(kGT) void k_pipe_gram(const PipeArgs a) {
           nxt.sq = pv[2 * kRowsWG + kn];
           nxt.tw = twp[gc ? kn * kRowsWG : 0];
         }
+        // row kk+2 from its helper, read speculatively (flag first, then the row): the helper puts the
+        // row a pivot needs next into G_s before anything else, right after the previous record appears,
+        // so it is normally there by now and the round trip is hidden behind the whole gain chain
+        int f_early = 0;
+        double r2 = 0.0;
+        if (has2) {
+          f_early = poll ? g_ctl_lane(&ctl[cHProg + (kk & 1)]) : 0;
+          r2 = G_s[(kk + 2) * kRowsWG + lane];
+        }
         const bool act = ((asm_mask >> kk) & 1) != 0;
         if (__builtin_expect(((__ballot(!(g > thr)) >> kk) & 1) != 0 && !EFA_EXP(0x70), 0)) {  // the downdate may have cancelled
           if (lane == 0) give_up();
@@ -427,14 +436,6 @@ __global__ __launch_bounds__(kGT) void k_pipe_gram(const PipeArgs a) {
         const double km = act ? kc * rden : 0.0;                      // :119
         const double kb = beta * km;                                  // :136
         const double innov = valk - xmk;                              // :85
-        // row kk+2 from its helper, read speculatively here (the helper had the whole gain chain above to
-        // hand it over; the round trip overlaps the publication below): flag first, then the row
-        int f_early = 0;
-        double r2 = 0.0;
-        if (has2) {
-          f_early = poll ? g_ctl_lane(&ctl[cHProg + (kk & 1)]) : 0;
-          r2 = G_s[(kk + 2) * kRowsWG + lane];
-        }
         s_gk[kk * kRowsWG + lane] = make_double2(g, kb);
         if (lane == 0) {
           double2* sc = reinterpret_cast<double2*>(s_sc + (size_t)kk * 4);
@@ -510,8 +511,8 @@ __global__ __launch_bounds__(kGT) void k_pipe_gram(const PipeArgs a) {
     // ---------------- helper waves: rows that become pivots later ----------------
     // helper h keeps the 32 rows of its parity in registers (lane = column) and applies each step's
     // rank-one downdate to those at least three rows ahead of the pivot; row kk+3 is handed to the
-    // pivot wave through G_s during step kk, a full step before the pivot needs it (the pivot applies
-    // the last two steps to it itself), so only the helpers' throughput matters, not their latency
+    // pivot wave through G_s at the start of step kk, a full step before the pivot needs it (the pivot
+    // applies the last two steps to it itself)
     const int h = wave - kVW - 1;  // 0, 1
     __builtin_amdgcn_s_setprio(2);  // measured: 2% faster Phase A with it, 3% slower if the pivot wave is raised too
     double gr[kRowsWG / 2];
@@ -528,15 +529,6 @@ __global__ __launch_bounds__(kGT) void k_pipe_gram(const PipeArgs a) {
         for (int q = 4 * q4; q < 4 * q4 + 4; ++q) gr[16 * H + q] = __builtin_fma(-kb, ga[q].x, gr[16 * H + q]);
 #pragma unroll
         for (int q = 4 * q4; q < 4 * q4 + 4; ++q) gr[16 * H + q] = __builtin_fma(-ga[q].y, t, gr[16 * H + q]);
-      }
-      if (kk + 3 >= 32 * H && kk + 3 < 32 * H + 32 && ((kk + 3) & 1) == h) {  // the hand-over row is one of these
-#pragma unroll
-        for (int q = 0; q < 16; ++q) {
-          const int i = 32 * H + 2 * q + h;
-          if (i == kk + 3) G_s[i * kRowsWG + lane] = gr[16 * H + q];
-        }
-        if (lane == 0) g_ctl_set(&ctl[cHProg + h], kk + 3);
-        EFA_GSTAMP(lane == 0 && !(a.debug & 8), own0 + kk, 6);
       }
     };
     for (int kk = 0; kk + 3 < nb; ++kk) {
@@ -564,14 +556,34 @@ __global__ __launch_bounds__(kGT) void k_pipe_gram(const PipeArgs a) {
       const double t = own.x - kb * Gkk;
       EFA_GSTAMP(lane == 0 && h == ((kk + 1) & 1) && !(a.debug & 8), own0 + kk, 5);
       EFA_GSTAMP(lane == 0 && h == 0 && (a.debug & 8), own0 + kk, 4);
-      // rows behind the pivot may be updated too (their registers are dead)
-      if (EFA_EXP(16)) {  // timing experiment: hand-over only
-        if (((kk + 3) & 1) == h) {
-          G_s[(kk + 3) * kRowsWG + lane] = gr[0];
-          if (lane == 0) g_ctl_set(&ctl[cHProg + h], kk + 3);
+      // The row the pivot needs next (kk+3) first and on its own -- one uniform read, the same two FMAs the
+      // bulk applies to it below (so the register copy ends up identical) -- so that it is in G_s well
+      // before the pivot's next step starts and the pivot's early read of it never has to be repeated.
+      if (((kk + 3) & 1) == h) {
+        const int hr = kk + 3;
+        const double2 gu = rec[hr];
+        double cur = 0.0;
+        switch (hr >> 1) {
+#define EFA_HR_CASE(R) \
+  case R:              \
+    cur = gr[R];       \
+    break;
+          EFA_HR_CASE(1) EFA_HR_CASE(2) EFA_HR_CASE(3) EFA_HR_CASE(4) EFA_HR_CASE(5) EFA_HR_CASE(6) EFA_HR_CASE(7)
+          EFA_HR_CASE(8) EFA_HR_CASE(9) EFA_HR_CASE(10) EFA_HR_CASE(11) EFA_HR_CASE(12) EFA_HR_CASE(13)
+          EFA_HR_CASE(14) EFA_HR_CASE(15) EFA_HR_CASE(16) EFA_HR_CASE(17) EFA_HR_CASE(18) EFA_HR_CASE(19)
+          EFA_HR_CASE(20) EFA_HR_CASE(21) EFA_HR_CASE(22) EFA_HR_CASE(23) EFA_HR_CASE(24) EFA_HR_CASE(25)
+          EFA_HR_CASE(26) EFA_HR_CASE(27) EFA_HR_CASE(28) EFA_HR_CASE(29) EFA_HR_CASE(30) EFA_HR_CASE(31)
+#undef EFA_HR_CASE
+          default: break;
         }
-        continue;
+        cur = __builtin_fma(-kb, gu.x, cur);
+        cur = __builtin_fma(-gu.y, t, cur);
+        G_s[hr * kRowsWG + lane] = cur;
+        if (lane == 0) g_ctl_set(&ctl[cHProg + h], hr);
+        EFA_GSTAMP(lane == 0 && !(a.debug & 8), own0 + kk, 6);
       }
+      // rows behind the pivot may be updated too (their registers are dead)
+      if (EFA_EXP(16)) continue;  // timing experiment: hand-over only
       if (kk + 3 < 32) downdate(rec, kb, t, kk, std::integral_constant<int, 0>());
       EFA_GSTAMP(lane == 0 && h == 0 && (a.debug & 8), own0 + kk, 5);
       downdate(rec, kb, t, kk, std::integral_constant<int, 1>());
