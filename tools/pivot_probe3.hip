@@ -187,5 +187,17 @@ int main() {
   RUNT(15, 512, lds, "all, 512-thread workgroup (6 waves exit at once)");
   RUNT(15, 512, 150 * 1024, "all, 512 threads, 150 KB of LDS allocated");
   RUNT(15, 128, 150 * 1024, "all, 128 threads, 150 KB of LDS allocated");
+  {  // wall-clock check of the tick unit
+    hipEvent_t e0, e1; (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
+    const int nb2 = 4000;
+    hipLaunchKernelGGL((k<15, 128>), dim3(1), dim3(128), lds, 0, nb2, out, cyc, status); (void)hipDeviceSynchronize();
+    (void)hipEventRecord(e0, 0);
+    hipLaunchKernelGGL((k<15, 128>), dim3(1), dim3(128), lds, 0, nb2, out, cyc, status);
+    (void)hipEventRecord(e1, 0); (void)hipDeviceSynchronize();
+    float ms; (void)hipEventElapsedTime(&ms, e0, e1);
+    (void)hipMemcpy(&c, cyc, 8, hipMemcpyDeviceToHost);
+    printf("wall check: %d blocks: %.3f ms wall = %.1f ns per step; %.0f ticks per step -> %.2f GHz tick rate\n", nb2, ms,
+           ms * 1e6 / nb2 / 64, c / (double)nb2 / 64, (c / (double)nb2 / 64) / (ms * 1e6 / nb2 / 64));
+  }
   return 0;
 }
