@@ -21,7 +21,7 @@ __device__ __forceinline__ void g_ctl_set(int* p, int v) {
 enum { cReady = 0, cBail = 1, cSReady = 2, cFwd = 3, cProg = 4, cHProg = 8 };
 constexpr int kRowsWG = 64;
 // MODE bits: 1 guard, 2 diag selects, 4 helper row hand-over (flag + row), 8 publication
-template <int MODE, int TPB>
+template <int MODE, int TPB, int BIG = 0>
 __global__ __launch_bounds__(TPB) void k(int nblocks, double* out, unsigned long long* cyc, int* status) {
   extern __shared__ __align__(16) double lds[];
   double* G_s = lds;                                   // [64][64]
@@ -37,6 +37,8 @@ __global__ __launch_bounds__(TPB) void k(int nblocks, double* out, unsigned long
   long budget = 4000000;
   int polls = 0;
   u64 total = 0;
+  double big[BIG > 0 ? BIG : 1];
+  for (int q = 0; q < BIG; ++q) big[q] = out[(threadIdx.x + q) & 1023];
   for (int blk = 0; blk < nblocks; ++blk) {
     __syncthreads();
     if (threadIdx.x < 16) ctl[threadIdx.x] = (threadIdx.x >= cProg) ? -1 : 0;
@@ -144,6 +146,8 @@ __global__ __launch_bounds__(TPB) void k(int nblocks, double* out, unsigned long
       }
       return true;
     };
+#pragma unroll
+    for (int q = 0; q < BIG; ++q) asm volatile("" : "+v"(big[q]));
     const u64 t0 = __builtin_amdgcn_s_memtime();
     {
       int kk = 0;
@@ -162,6 +166,9 @@ __global__ __launch_bounds__(TPB) void k(int nblocks, double* out, unsigned long
     total += t1 - t0;
     out[lane] = g + g1 + mu + xmv + o_pm + o_pv + o_in + o_rd + o_be + o_km;
   }
+  double sb = 0;
+  for (int q = 0; q < BIG; ++q) sb += big[q];
+  if (BIG > 0) out[threadIdx.x] = sb;
   if (threadIdx.x == 0) cyc[0] = total;
 }
 int main() {
@@ -187,6 +194,12 @@ int main() {
   RUNT(15, 512, lds, "all, 512-thread workgroup (6 waves exit at once)");
   RUNT(15, 512, 150 * 1024, "all, 512 threads, 150 KB of LDS allocated");
   RUNT(15, 128, 150 * 1024, "all, 128 threads, 150 KB of LDS allocated");
+#define RUNB(BIG, NAME) \
+  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k<15, 512, BIG>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(150 * 1024)); \
+  hipLaunchKernelGGL((k<15, 512, BIG>), dim3(1), dim3(512), 150 * 1024, 0, nblocks, out, cyc, status); (void)hipDeviceSynchronize(); \
+  (void)hipMemcpy(&c, cyc, 8, hipMemcpyDeviceToHost); printf("%-56s %.0f cycles per step\n", NAME, c / (double)nblocks / 64);
+  RUNB(40, "all, 512 threads, +80 live VGPRs");
+  RUNB(90, "all, 512 threads, +180 live VGPRs");
   {  // wall-clock check of the tick unit
     hipEvent_t e0, e1; (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
     const int nb2 = 4000;
