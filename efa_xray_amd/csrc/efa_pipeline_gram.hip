@@ -471,6 +471,9 @@ __global__ __launch_bounds__(kGT) void k_pipe_gram(const PipeArgs a) {
         return true;
       };
       EFA_BLOCKSTAMP(lane == 0, 0);
+#ifdef EFA_PIPE_BLOCKTIME
+      if (a.dbg != nullptr && lane == 0) a.dbg[(size_t)own0 * 8 + 6] = __builtin_amdgcn_s_memrealtime();
+#endif
       {
         int kk = 0;
         bool ok = true;
@@ -489,6 +492,9 @@ __global__ __launch_bounds__(kGT) void k_pipe_gram(const PipeArgs a) {
         bailed = !ok;
       }
       EFA_BLOCKSTAMP(lane == 0, 1);
+#ifdef EFA_PIPE_BLOCKTIME
+      if (a.dbg != nullptr && lane == 0) a.dbg[(size_t)own0 * 8 + 7] = __builtin_amdgcn_s_memrealtime();
+#endif
       pm[kRowsWG + lane] = xmv;  // obs-space means of all 64 rows after the block, back to the vector waves
       __syncthreads();  // B3
       if (!bailed && g_ctl(&ctl[cBail]) == 0 && is_ob) {
