@@ -470,6 +470,40 @@ def test_headline_size_properties():
         X.free()
 
 
+def test_persistent_phase_a_at_its_residency_limit():
+    """16 284 obs x 100 members (+100 carried transform rows = 16 384 rows = 256 co-resident workgroups, one per
+    CU): the persistent Phase-A launch (both leaders) against the per-batch kernels."""
+    ctx = _ctx()
+    M, P = 100, 16284
+    rng = np.random.default_rng(21)
+    HX = 3.0 * rng.standard_normal((P, M))
+    val = HX.mean(axis=1) + rng.standard_normal(P)
+    err = rng.uniform(0.5, 2.0, P)
+    asm = rng.random(P) < 0.95
+    res = {}
+    try:
+        for name, pipe, gram in (("batch", 0, 0), ("chain", 1, 0), ("gram", 1, 1)):
+            ctx.set_option("pipeline", pipe)
+            ctx.set_option("gram", gram)
+            ctx.set_option("path", 0)
+            Yp = ctx.to_device(HX)
+            ym = ctx.empty((P,))
+            ctx.form_perts(P, M, Yp, ym, Yp)
+            d = ctx.obs_phase(M, P, ym, Yp, val, err, asm)
+            assert ctx.get_option("phase_a_kind") == {"batch": 2, "chain": 1, "gram": 3}[name]
+            res[name] = (Yp.download(), ym.download(), d)
+        for name in ("chain", "gram"):
+            assert_parity(res[name][0], res["batch"][0], name + " obs perturbations")
+            assert_parity(res[name][1], res["batch"][1], name + " obs means")
+            for key in ("prior_mean", "prior_var", "post_mean", "post_var"):
+                assert_parity(res[name][2][key], res["batch"][2][key], name + " " + key)
+            assert np.array_equal(res[name][2]["assimilated"], res["batch"][2]["assimilated"])
+    finally:
+        ctx.set_option("pipeline", 1)
+        ctx.set_option("gram", GRAM_DEFAULT)
+        ctx.set_option("path", 0)
+
+
 def test_helper_kernels_vs_oracle():
     ctx = _ctx()
     rng = np.random.default_rng(8)
