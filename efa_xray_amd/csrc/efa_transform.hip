@@ -48,21 +48,30 @@ struct TShape {
 // by a select at the point of use) and the prefetch is unconditional, so the compiler can
 // keep the next tile's 16-byte loads in flight behind counted vmcnt waits while the current
 // tile is multiplied.  With conditional loads it falls back to vmcnt(0) and the overlap is lost.
-template <int NU>
+// HALF: the last chunk holds at most four members (M % 8 in 1..4).  Lane-group g then loads member
+// 8(NU-1)+g alone, so the chunk is ONE K step of the matrix core instead of two half-empty ones
+// (M = 100: 25 steps instead of 26).
+template <int NU, bool HALF>
 __device__ __forceinline__ void load_tile(const double* __restrict__ X, long row_clamped, int M, int g,
                                           double (&a)[2 * NU]) {
   const double* p = X + (size_t)row_clamped * M;
 #pragma unroll
   for (int u = 0; u < NU; ++u) {
-    int m0 = 8 * u + 2 * g;
-    if (u == NU - 1) m0 = (m0 < M) ? m0 : M - 2;  // last chunk may be partial: clamp the address
-    const double2 v = *reinterpret_cast<const double2*>(p + m0);
-    a[2 * u] = v.x;
-    a[2 * u + 1] = v.y;
+    if (HALF && u == NU - 1) {
+      const int m = 8 * u + g;
+      a[2 * u] = p[(m < M) ? m : M - 1];
+      a[2 * u + 1] = 0.0;
+    } else {
+      int m0 = 8 * u + 2 * g;
+      if (u == NU - 1) m0 = (m0 < M) ? m0 : M - 2;  // last chunk may be partial: clamp the address
+      const double2 v = *reinterpret_cast<const double2*>(p + m0);
+      a[2 * u] = v.x;
+      a[2 * u + 1] = v.y;
+    }
   }
 }
 
-template <int NU, bool FUSED>
+template <int NU, bool FUSED, bool HALF>
 __global__ __launch_bounds__(kThreadsT) void k_transform(const TransformArgs p) {
   using Sh = TShape<NU>;
   constexpr int NT = Sh::NT;
@@ -78,7 +87,7 @@ __global__ __launch_bounds__(kThreadsT) void k_transform(const TransformArgs p) 
     const int s = st / NT;
     const int u = s >> 1, h = s & 1;
     const int g = l >> 4, n = l & 15;
-    const int m = 8 * u + 2 * g + h;
+    const int m = (HALF && u == NU - 1) ? (h == 0 ? 8 * u + g : M) : 8 * u + 2 * g + h;  // (row M: never used, stays 0)
     const int j = 16 * t + n;
     double v = 0.0;
     if (m < M) {
@@ -91,18 +100,21 @@ __global__ __launch_bounds__(kThreadsT) void k_transform(const TransformArgs p) 
 
   const int lane = tid & 63;
   const int g = lane >> 4, n = lane & 15;
+#ifdef EFA_T_CLOCKSTAMP  /* tools/transform_clock.py: shader clock over the kernel (non-fused launches only) */
+  const unsigned long long tm0 = __builtin_amdgcn_s_memtime(), tr0 = __builtin_amdgcn_s_memrealtime();
+#endif
   const long ntiles = (p.nrows + 15) / 16;
   const long wave = (long)blockIdx.x * (kThreadsT / 64) + (tid >> 6);
   const long nwaves = (long)gridDim.x * (kThreadsT / 64);
   const int tM = M >> 4, nM = M & 15;  // tile / lane column holding the mean increment
   const long last_row = p.nrows - 1;
-  const bool last_ok = (8 * (NU - 1) + 2 * g) < M;  // this lane's slots of the last chunk are real members
+  const bool last_ok = (HALF ? (8 * (NU - 1) + g) : (8 * (NU - 1) + 2 * g)) < M;  // this lane's slots of the last chunk are real members
 
   double a[2 * NU], an[2 * NU];
   long tile = wave;
   if (tile < ntiles) {
     const long r = tile * 16 + n;
-    load_tile<NU>(p.Xin, r < last_row ? r : last_row, M, g, a);
+    load_tile<NU, HALF>(p.Xin, r < last_row ? r : last_row, M, g, a);
   }
 
   while (tile < ntiles) {
@@ -118,7 +130,7 @@ __global__ __launch_bounds__(kThreadsT) void k_transform(const TransformArgs p) 
     }
     if (kPrefetchT) {  // prefetch (the last iteration harmlessly re-reads its own tile)
       const long r = (next < ntiles ? next : tile) * 16 + n;
-      load_tile<NU>(p.Xin, r < last_row ? r : last_row, M, g, an);
+      load_tile<NU, HALF>(p.Xin, r < last_row ? r : last_row, M, g, an);
     }
     if (!last_ok) {
       a[2 * NU - 2] = 0.0;
@@ -137,14 +149,14 @@ __global__ __launch_bounds__(kThreadsT) void k_transform(const TransformArgs p) 
 #pragma unroll
       for (int c = 0; c < 2 * NU - 2; ++c) a[c] -= rmean;
       a[2 * NU - 2] = last_ok ? a[2 * NU - 2] - rmean : 0.0;
-      a[2 * NU - 1] = last_ok ? a[2 * NU - 1] - rmean : 0.0;
+      a[2 * NU - 1] = (last_ok && !HALF) ? a[2 * NU - 1] - rmean : 0.0;
     }
 
     v4f64 acc[NT];
 #pragma unroll
     for (int t = 0; t < NT; ++t) acc[t] = (v4f64){0.0, 0.0, 0.0, 0.0};
 #pragma unroll
-    for (int s = 0; s < 2 * NU; ++s) {
+    for (int s = 0; s < (HALF ? 2 * NU - 1 : 2 * NU); ++s) {
 #pragma unroll
       for (int t = 0; t < NT; ++t) {
         const double b = Bs[((size_t)s * NT + t) * 64 + lane];
@@ -204,18 +216,24 @@ __global__ __launch_bounds__(kThreadsT) void k_transform(const TransformArgs p) 
       for (int c = 0; c < 2 * NU; ++c) a[c] = an[c];
     } else if (next < ntiles) {
       const long r = next * 16 + n;
-      load_tile<NU>(p.Xin, r < last_row ? r : last_row, M, g, a);
+      load_tile<NU, HALF>(p.Xin, r < last_row ? r : last_row, M, g, a);
     }
     tile = next;
   }
+#ifdef EFA_T_CLOCKSTAMP
+  if (!FUSED && blockIdx.x == 0 && tid == 0) {
+    p.xout[0] = (double)(__builtin_amdgcn_s_memtime() - tm0);
+    p.xout[1] = (double)(__builtin_amdgcn_s_memrealtime() - tr0);
+  }
+#endif
 }
 
-template <int NU, bool FUSED>
+template <int NU, bool FUSED, bool HALF>
 hipError_t transform_launch(const TransformArgs& a, hipStream_t s) {
   using Sh = TShape<NU>;
   const size_t lds = Sh::lds_doubles * sizeof(double);
   if (lds > 64 * 1024) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_transform<NU, FUSED>),
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_transform<NU, FUSED, HALF>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
   }
@@ -224,13 +242,16 @@ hipError_t transform_launch(const TransformArgs& a, hipStream_t s) {
   long grid = (ntiles + EFA_T_WAVES - 1) / EFA_T_WAVES;
   if (grid > 256L * per_cu) grid = 256L * per_cu;
   if (grid < 1) grid = 1;
-  hipLaunchKernelGGL((k_transform<NU, FUSED>), dim3((unsigned)grid), dim3(kThreadsT), lds, s, a);
+  hipLaunchKernelGGL((k_transform<NU, FUSED, HALF>), dim3((unsigned)grid), dim3(kThreadsT), lds, s, a);
   return hipGetLastError();
 }
 
 template <int NU>
 hipError_t transform_nu(const TransformArgs& a, hipStream_t s) {
-  return a.fused_members ? transform_launch<NU, true>(a, s) : transform_launch<NU, false>(a, s);
+  const int rem = a.M % 8;
+  if (rem != 0 && rem <= 4)
+    return a.fused_members ? transform_launch<NU, true, true>(a, s) : transform_launch<NU, false, true>(a, s);
+  return a.fused_members ? transform_launch<NU, true, false>(a, s) : transform_launch<NU, false, false>(a, s);
 }
 
 }  // namespace
