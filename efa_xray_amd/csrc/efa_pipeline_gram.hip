@@ -4,10 +4,11 @@
 // obs rows, rows resident in registers, sentinel-validated agent-scope trajectory records), but
 // the LEADER no longer carries vectors on its serial chain.  In efa_pipeline.hip every step of
 // the chain contains an M-long LDS read, a dot product with a cross-lane reduction, the gain
-// scalars and an M-long LDS write (~2400 cycles).  Here, when a workgroup's turn comes:
+// scalars and an M-long LDS write.  Here, when a workgroup's turn comes:
 //
 //   1. its 64 rows are written once to an LDS tile and G = Y Y^T (the 64 x 64 matrix of their
 //      dot products) is formed on the matrix cores (v_mfma_f64_16x16x4_f64, ~3 us);
+//      the two helper waves keep the pending rows of G in registers;
 //   2. ONE "pivot" wave runs the serial recurrence in Gram space, lane j = row j: for ob k
 //         var_k   = G_kk/M - mean_k^2                       (np.var, ddof 0: ensrf.py:69)
 //         kmat_j  = w_jk * G_kj/(M-1) / kdenom_k            (:95,:115,:119) for all 64 rows at once
@@ -15,8 +16,10 @@
 //         G_ij   -= kb_j G_ki + kb_i (G_kj - kb_j G_kk)     (what y_i -= kb_i ye_k does to the dots)
 //      no dot products, no reductions, no vectors: lane k's values are fetched with v_readlane.
 //      Two helper waves apply the rank-one downdate to the rows that become pivots later;
-//   3. the four vector waves follow behind: with kmat_i known, a step is a pure axpy
-//      y_i -= kb_i ye_k, and ye_k itself is just row k after its own axpys;
+//   3. the four vector waves follow behind: with kb_i known, a step is a pure axpy
+//      y_i -= kb_i ye_k, and ye_k itself is just row k after its own axpys.  For the block the rows
+//      sit in matrix-core accumulator tiles: the next rows to be published are updated step by
+//      step, all others by one rank-4 MFMA per tile and four steps;
 //   4. the loader wave forwards (ye_k from the vector ring, scalars from the pivot wave) to
 //      global memory for the other workgroups, which consume them exactly as before.
 //
