@@ -3,18 +3,23 @@
 
     python bench.py --gpus 1 --steps 5 --warmup 2
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
-        --master-port P bench.py --gpus N --steps K --warmup W
+        --master-port P bench.py --gpus N --steps K --warmup W [--scaling strong --workload cfg4]
 
-One "step" = one full serial-EnSRF assimilation cycle of the headline workload
-(BASELINE.json metric: 1e7 state x 100 members, 1e4 obs, float64, no
-localisation) on data already resident in HBM: forward-operator gather of the
-obs-space priors, (N>1: RCCL all-reduce of them), Phase A over the obs block,
-and the state sweep prior-members -> posterior-members.  With N GPUs every rank
-holds its own 1e7-row shard of an N*1e7-row state (weak scaling) and
-assimilates all P obs into it; value = P*N / time.
+One "step" = one full serial-EnSRF assimilation cycle on data already resident in HBM, run
+through the product's multi-GPU class (`efa_xray_amd.distributed.ShardedEnSRF` on a
+`HipEngine`, also at N=1): forward-operator gather of the obs-space priors, (N>1: ONE RCCL
+all-reduce of them), obs-space priors, Phase A over the obs block, and the state sweep
+prior members -> posterior members.
 
-Prints ONE JSON line on rank 0 (fields documented in DESIGN.md section
-"Measurement").
+The state is ONE global grid partitioned by (y,x) column into contiguous equal blocks, last
+rank takes the remainder (`column_bounds`; reference precedent ensemble.py:98-106).
+  --scaling weak   (default; the headline): the global state has N x (rows of the workload), every
+                   rank holds the workload's rows; value = P*N / time (every ob is assimilated into
+                   N shards' worth of state).
+  --scaling strong: the global state is the workload's (configs[3]: the 38.5 M-row 3-D state), split
+                   N ways; value = P / time.
+
+Prints ONE JSON line on rank 0 (fields documented in DESIGN.md section 6).
 """
 import argparse
 import json
@@ -28,17 +33,21 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
-HBM_PEAK_GBPS = 8000.0      # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
-FP64_PEAK_TFLOPS = 78.6     # MI355X fp64 vector = matrix peak (spec)
+HBM_PEAK_GBPS = 8000.0      # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy ceiling)
+HBM_COPY_GBPS = 6290.0
+FP64_PEAK_TFLOPS = 78.6     # MI355X fp64 vector = matrix peak (spec, at 2.4 GHz)
 
 WORKLOADS = {
-    # name: rows per GPU, members, obs, loc, (n_lead, ny, nx) for GC
+    # name: rows (global for strong scaling, per GPU for weak), members, obs, loc, (n_lead, ny, nx) for GC
     "headline": dict(rows=10_000_000, M=100, P=10_000, loc=None,
                      desc="headline (BASELINE.json metric): 1e7 state x 100 members x 1e4 obs, float64, loc=None"),
     "cfg2": dict(rows=512 * 512, M=50, P=1_000, loc=None,
                  desc="configs[1]: 512x512 grid x 50 members x 1000 obs, float64, loc=None"),
     "cfg3": dict(rows=4 * 37 * 361 * 720, M=80, P=5_000, loc="GC", n_lead=148, ny=361, nx=720, radius_km=1000.0,
                  desc="configs[2]: (lat=361,lon=720,lev=37,vars=4) x 80 members x 5000 obs, GC 1000 km"),
+    "cfg4": dict(rows=4 * 37 * 361 * 720, M=100, P=10_000, loc="GC", n_lead=148, ny=361, nx=720, radius_km=1000.0,
+                 desc="configs[3]: (lat=361,lon=720,lev=37,vars=4) x 100 members x 10000 obs, GC 1000 km, "
+                      "state sharded by grid point"),
     "small": dict(rows=200_000, M=100, P=500, loc=None, desc="small smoke workload"),
     "small_gc": dict(rows=8 * 90 * 180, M=40, P=300, loc="GC", n_lead=8, ny=90, nx=180, radius_km=1000.0,
                      desc="small GC smoke workload"),
@@ -51,65 +60,83 @@ def parse_args():
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--workload", default="headline", choices=sorted(WORKLOADS))
-    ap.add_argument("--rows", type=int, default=None, help="override rows per GPU")
+    ap.add_argument("--scaling", default="weak", choices=["weak", "strong"])
+    ap.add_argument("--rows", type=int, default=None, help="override the workload's row count (loc=None workloads)")
     ap.add_argument("--obs", type=int, default=None, help="override observation count")
     ap.add_argument("--path", default="auto", choices=["auto", "sweep", "transform"])
     ap.add_argument("--obs-batch", type=int, default=None)
     ap.add_argument("--gram", type=int, default=None, help="Phase-A leader in Gram space (library default if omitted)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-rows", type=int, default=1_000_000)
-    ap.add_argument("--cpu-obs", type=int, default=4)
+    ap.add_argument("--cpu-rows", type=int, default=0, help="rows of the CPU-baseline sample (0: sized to --cpu-seconds)")
+    ap.add_argument("--cpu-obs", type=int, default=8, help="timed observations of the CPU baseline (BASELINE.md 3)")
+    ap.add_argument("--cpu-warm", type=int, default=2, help="warm-up observations of the CPU baseline")
+    ap.add_argument("--cpu-seconds", type=float, default=25.0, help="time budget of the CPU baseline")
     return ap.parse_args()
 
 
-def cpu_baseline(sample_X, sample_HX, val, err, rows_full, loc_kw):
-    """The oracle (NumPy restatement of the reference, faithful_cost=True so it
-    performs the reference's passes over the matrix) timed on this box's host
-    cores on a bounded sample, scaled linearly in rows (per-ob cost
-    is linear in rows and independent of the ob index)."""
+# ----------------------------------------------------------------------------------------------
+# CPU baseline: the oracle, on this box's host cores, on a bounded sample
+# ----------------------------------------------------------------------------------------------
+def _oracle_prefix_seconds(orc, xbm, Xbp, rows, val, err, n, loc_kw):
+    """Wall time of assimilating the first n obs of the sample (augmented rows trimmed to n)."""
+    A = rows + n
+    kw = {}
+    if loc_kw:
+        kw = dict(loc="GC", ob_lat=loc_kw["ob_lat"][:n], ob_lon=loc_kw["ob_lon"][:n], ob_halfwidth=loc_kw["hw"][:n],
+                  grid_lat=loc_kw["lat"], grid_lon=loc_kw["lon"], state_shape=loc_kw["state_shape"])
+    t0 = time.perf_counter()
+    orc.ensrf_update(xbm[:A], Xbp[:A], rows, val[:n], err[:n], np.ones(n, dtype=bool), faithful_cost=True, **kw)
+    return time.perf_counter() - t0
+
+
+def cpu_baseline(fetch_sample, rows_full, M, nwarm, ntimed, budget_s, fixed_rows, loc_info):
+    """`fetch_sample(n_units)` returns (X_sample, HX_sample, val, err, loc_kw, rows_sample) for the first n_units
+    rows (loc=None) or latitude circles (GC) of the bench's own synthetic state.  The oracle runs in
+    faithful_cost mode (the reference's one-hot row picks and temporaries, i.e. its memory traffic) for
+    `nwarm` warm-up obs, then `ntimed` timed obs (2 + 8); the per-ob cost is linear in rows and
+    independent of the ob index, so the sample's rate is scaled by rows_sample / rows_full.
+    The sample is the largest that keeps the whole measurement inside `budget_s` (probed on a small one)."""
     from oracle import ensrf_oracle as orc
     try:
         from threadpoolctl import threadpool_info
         cores = max([p.get("num_threads", 1) for p in threadpool_info()] or [1])
     except Exception:
         cores = os.cpu_count() or 1
-    nwarm = 1
-    P = sample_HX.shape[0]
-    rows = sample_X.shape[0]
-    xbm, Xbp = orc.format_prior_state(sample_X, sample_HX)
-    asm = np.ones(P, dtype=bool)
-    # time the loop on a prefix of nwarm obs and on all P obs; the difference is P-nwarm warm obs
-    t0 = time.perf_counter()
-    _run_prefix(orc, xbm, Xbp, rows, val, err, asm, nwarm, loc_kw)
-    t1 = time.perf_counter()
-    _run_prefix(orc, xbm, Xbp, rows, val, err, asm, P, loc_kw)
-    t2 = time.perf_counter()
-    per_ob = ((t2 - t1) - (t1 - t0)) / (P - nwarm)
-    obs_per_s_sample = 1.0 / per_ob
-    return dict(value=obs_per_s_sample * rows / rows_full, unit="obs/s", cores=int(cores), kind="port",
-                sample="NumPy oracle (faithful_cost) on the first %d rows x %d members of the same synthetic "
-                       "state, %d obs timed after %d warm-up (%.2f s/ob), scaled linearly to %d rows"
-                       % (rows, sample_X.shape[1], P - nwarm, nwarm, per_ob, rows_full))
+    unit_rows = loc_info["unit_rows"]          # rows per sample unit (1, or n_lead*nx for a latitude circle)
+    max_units = loc_info["max_units"]
+    nobs = nwarm + ntimed
 
+    def measure(units):
+        Xs, HXs, val, err, loc_kw, rows_s = fetch_sample(units, nobs)
+        xbm, Xbp = orc.format_prior_state(Xs, HXs)
+        _oracle_prefix_seconds(orc, xbm, Xbp, rows_s, val, err, nwarm, loc_kw)           # warm-up, untimed
+        t_warm = _oracle_prefix_seconds(orc, xbm, Xbp, rows_s, val, err, nwarm, loc_kw)  # the same obs again
+        t_all = _oracle_prefix_seconds(orc, xbm, Xbp, rows_s, val, err, nobs, loc_kw)    # ... plus the timed ones
+        return max(t_all - t_warm, 1e-9) / ntimed, rows_s
 
-def _run_prefix(orc, xbm, Xbp, rows, val, err, asm, n, loc_kw):
-    """Assimilate the first n obs of the sample (augmented rows trimmed to n)."""
-    A = rows + n
-    kw = {}
-    if loc_kw:
-        kw = dict(loc="GC", ob_lat=loc_kw["ob_lat"][:n], ob_lon=loc_kw["ob_lon"][:n],
-                  ob_halfwidth=loc_kw["hw"][:n], grid_lat=loc_kw["lat"], grid_lon=loc_kw["lon"],
-                  state_shape=loc_kw["state_shape"])
-    return orc.ensrf_update(xbm[:A], Xbp[:A], rows, val[:n], err[:n], asm[:n], faithful_cost=True, **kw)
+    if fixed_rows:
+        units = max(1, min(max_units, fixed_rows // unit_rows))
+    else:
+        probe_units = max(1, min(max_units, 200_000 // unit_rows))
+        per_ob, rows_p = measure(probe_units)
+        per_row = per_ob / rows_p
+        # the measurement costs (3*nwarm + ntimed) obs plus forming the sample (~2 obs' worth)
+        units = int(budget_s / (per_row * unit_rows * (3 * nwarm + ntimed + 2)))
+        units = max(probe_units, min(max_units, units))
+    per_ob, rows_s = measure(units)
+    return dict(value=(1.0 / per_ob) * rows_s / rows_full, unit="obs/s", cores=int(cores), kind="port",
+                sample="NumPy oracle (faithful_cost: the reference's passes and temporaries) on the first %d rows x %d "
+                       "members of the same synthetic state, %d warm-up + %d timed obs (%.3f s/ob on the sample), scaled "
+                       "linearly to %d rows" % (rows_s, M, nwarm, ntimed, per_ob, rows_full))
 
 
 def load_traffic(workload, path_name):
-    """HBM bytes per launch of the dominant kernel from a separate rocprofv3
-    --pmc pass (profiles/traffic.json, written by tools/prof_summary.py)."""
+    """HBM bytes per launch of the state-sweep kernel from separate rocprofv3 --pmc passes
+    (profiles/traffic.json, written by tools/prof_summary.py; FETCH_SIZE doubled as
+    MI355X_MICROARCH.md prescribes for gfx950 wide streaming reads)."""
     p = os.path.join(ROOT, "profiles", "traffic.json")
     try:
-        t = json.load(open(p))
-        return t.get("%s:%s" % (workload, path_name))
+        return json.load(open(p)).get("%s:%s" % (workload, path_name))
     except Exception:
         return None
 
@@ -126,9 +153,10 @@ def main():
         if args.gpus != 1 or world != 1:
             sys.exit(2)
 
-    import torch            # plumbing only: device selection, RCCL, barriers
+    import torch            # plumbing only: device memory, the stream, RCCL, barriers
     import torch.distributed as dist
     from efa_xray_amd import _lib
+    from efa_xray_amd.distributed import ShardedEnSRF, HipEngine
 
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
@@ -137,70 +165,63 @@ def main():
 
     wl = dict(WORKLOADS[args.workload])
     if args.rows:
-        wl["rows"] = args.rows
         if wl.get("loc"):
             raise SystemExit("--rows cannot be combined with a GC workload")
+        wl["rows"] = args.rows
     if args.obs:
         wl["P"] = args.obs
-    rows, M, P = wl["rows"], wl["M"], wl["P"]
-    loc = wl["loc"]
-    row_offset = rank * rows
-    rows_global = rows * world
+    M, P, loc = wl["M"], wl["P"], wl["loc"]
+    strong = args.scaling == "strong"
 
-    ctx = _lib.Context(local_rank)
-    ctx.set_stream(torch.cuda.current_stream().cuda_stream)
+    # ---- the global grid and this rank's columns ------------------------------------------------
+    if loc == "GC":
+        n_lead, ny, nx = wl["n_lead"], wl["ny"], wl["nx"]
+        nx_g = nx if strong else nx * world                  # weak: N times as many longitudes on the same globe
+        lat2, lon2 = np.meshgrid(np.linspace(-90, 90, ny), np.linspace(0, 360 - 360.0 / nx_g, nx_g), indexing="ij")
+        glat, glon = lat2.reshape(-1), lon2.reshape(-1)
+        ncol_g = ny * nx_g
+    else:
+        n_lead = 1
+        ncol_g = wl["rows"] if strong else wl["rows"] * world
+        glat = glon = None
+    rows_g = n_lead * ncol_g
+
+    eng = HipEngine(local_rank)
+    ctx = eng.ctx
     ctx.set_option("path", {"auto": 0, "sweep": 1, "transform": 2}[args.path])
     if args.obs_batch:
         ctx.set_option("obs_batch", args.obs_batch)
     if args.gram is not None:
         ctx.set_option("gram", args.gram)
     ctx.set_option("timing", 1)
+    sh = ShardedEnSRF(eng, n_lead, ncol_g, M, rank=rank, world_size=world)
+    rows = sh.rows_local
+    ncol_l = sh.hi - sh.lo
 
-    # ---- synthetic inputs, generated on device per shard -------
+    # ---- synthetic inputs, generated on device per shard; keyed by GLOBAL row ----
     seed = 1000 + sorted(WORKLOADS).index(args.workload)
-    X = torch.empty((rows, M), dtype=torch.float64, device=dev)
-    post = torch.empty((rows, M), dtype=torch.float64, device=dev)
-    ctx.fill_synthetic(rows, row_offset, M, seed, 3.0, X.data_ptr())
+    X = eng.empty((rows, M))
+    post = eng.empty((rows, M))
+    for lead in range(n_lead):   # local rows of one lead are one contiguous run of global rows
+        ctx.fill_synthetic(ncol_l, lead * ncol_g + sh.lo, M, seed, 3.0, X.data_ptr() + lead * ncol_l * M * 8)
     rng = np.random.default_rng(3000 + seed)
-    pick = rng.choice(rows_global, P, replace=False).astype(np.int64)
+    pick = rng.choice(rows_g, P, replace=False).astype(np.int64)
     idx = pick[:, None].copy()
     wts = np.ones((P, 1))
     err = np.ones(P)
-    asm = np.ones(P, dtype=bool)
-    loc_mode = _lib.LOC_GC if loc == "GC" else _lib.LOC_NONE
-    ob_lat = ob_lon = hw = glat = glon = None
-    n_lead = 1
-    loc_kw = None
+    ob = dict(value=None, error=err, assim=np.ones(P, dtype=bool))
     if loc == "GC":
-        # shard by (y,x) columns: this rank owns columns [c0, c0+ncol) of the global ny*nx*world grid
-        n_lead, ny, nx = wl["n_lead"], wl["ny"], wl["nx"]
-        lat2, lon2 = np.meshgrid(np.linspace(-90, 90, ny), np.linspace(0, 360 - 360.0 / nx, nx), indexing="ij")
-        glat, glon = lat2.reshape(-1), lon2.reshape(-1)
-        ncol = ny * nx
-        # weak scaling: every rank holds a full copy-sized grid shard of a world-times-larger state
-        col = (pick % rows) % ncol
-        ob_lat, ob_lon = glat[col], glon[col]
-        hw = np.full(P, wl["radius_km"])
-        loc_kw = dict(ob_lat=ob_lat, ob_lon=ob_lon, hw=hw)
-    HX = torch.empty((P, M), dtype=torch.float64, device=dev)
-    ym = torch.empty((P,), dtype=torch.float64, device=dev)
+        col = pick % ncol_g
+        ob.update(loc="GC", lat=glat[col], lon=glon[col], halfwidth=np.full(P, wl["radius_km"]))
 
-    def forward():
-        ctx.forward_stencil(rows, row_offset, M, X.data_ptr(), idx, wts, HX.data_ptr())
-        if world > 1:
-            dist.all_reduce(HX, op=dist.ReduceOp.SUM)      # the one exchange step
-
-    forward()
+    HX0 = sh.partial_estimates(X, idx, wts)
+    sh.all_reduce_sum(HX0)
     torch.cuda.synchronize()
-    hx_host = HX.cpu().numpy()
-    val = hx_host.mean(axis=1) + np.random.default_rng(4000 + seed).standard_normal(P) * np.sqrt(err)
+    hx_host = HX0.cpu().numpy()
+    ob["value"] = hx_host.mean(axis=1) + np.random.default_rng(4000 + seed).standard_normal(P) * np.sqrt(err)
 
     def step():
-        forward()
-        ctx.form_perts(P, M, HX.data_ptr(), ym.data_ptr(), HX.data_ptr())
-        d = ctx.obs_phase(M, P, ym.data_ptr(), HX.data_ptr(), val, err, asm, loc_mode, ob_lat, ob_lon, hw)
-        ctx.state_cycle(rows, M, X.data_ptr(), post.data_ptr(), glat, glon, n_lead)
-        return d
+        return sh.update(X, post, idx, wts, ob, glat, glon)
 
     def sync_all():
         if world > 1:
@@ -229,64 +250,113 @@ def main():
         elapsed = float(tt.item())
     n_active = int(d["assimilated"].sum())
 
-    # sanity: the posterior must be finite and the variance must have shrunk
+    # sanity: the posterior must be finite
     chk = post[:4096].cpu().numpy()
     assert np.isfinite(chk).all(), "non-finite posterior"
 
     if rank == 0:
-        ms_per_step = 1e3 * elapsed / args.steps
-        value = n_active * world / (elapsed / args.steps)
-        bytes_per_ob = 16.0 * rows * (M + 1)                 # per-shard algorithmic bytes
+        sec_per_step = elapsed / args.steps
+        ms_per_step = 1e3 * sec_per_step
+        value = n_active * (1 if strong else world) / sec_per_step
         path_name = {1: "sweep", 2: "transform"}.get(path_taken, "sweep")
-        avg_launch_ms = state_ms / max(launches, 1)
-        obs_per_launch = n_active * args.steps / max(launches, 1)
-        achieved = bytes_per_ob * obs_per_launch / (avg_launch_ms * 1e-3) / 1e9
-        phys_bytes = 16.0 * rows * M if path_name == "transform" else 16.0 * rows * (M + 1)
-        flops_launch = (2.0 * rows * M * (M + 1)) if path_name == "transform" else 4.0 * rows * M * obs_per_launch
-        out = {
-            "metric": "obs assimilated/sec on cov+update (EnSRF cycle, %d state x %d members x %d obs)" % (rows, M, P),
-            "value": value, "unit": "obs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f64", "data": "synthetic",
-            "config": {"workload": wl["desc"], "rows_per_gpu": rows, "members": M, "obs": P,
-                       "loc": loc or "none", "path": path_name, "obs_batch": ctx.get_option("obs_batch"),
-                       "phase_a": {1: "pipeline", 2: "per-batch", 3: "pipeline-gram"}.get(ctx.get_option("phase_a_kind"), "?"),
-                       "sharding": "state rows by grid point, obs block replicated, one all-reduce of HX per cycle"},
-            "GBps_algorithmic": bytes_per_ob * n_active * world / (elapsed / args.steps) / 1e9,
-            "phase_ms": {"obs_phase": obs_ms / args.steps, "state_phase": state_ms / args.steps},
-            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBPS, "traffic": load_traffic(args.workload, path_name),
-                         "kernel": "k_transform" if path_name == "transform" else "k_sweep",
-                         "avg_launch_ms": avg_launch_ms, "obs_per_launch": obs_per_launch,
-                         "launch_physical_min_bytes": phys_bytes,
-                         "launch_physical_GBps": phys_bytes / (avg_launch_ms * 1e-3) / 1e9,
-                         "launch_physical_frac": phys_bytes / (avg_launch_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS,
-                         "launch_fp64_TFLOPs": flops_launch / (avg_launch_ms * 1e-3) / 1e12,
-                         "launch_fp64_frac": flops_launch / (avg_launch_ms * 1e-3) / 1e12 / FP64_PEAK_TFLOPS},
-        }
-        # Phase A (the serial chain) is the longer of the two launches at the headline size: it moves ~95 MB
-        # and is bound by the step latency of ONE workgroup, so neither roofline applies; reported for scale
         kind = ctx.get_option("phase_a_kind")
-        out["phase_a"] = {"kernel": {1: "k_pipe", 2: "k_diag+k_sweep", 3: "k_pipe_gram"}.get(kind, "?"),
-                          "bound": "latency of the serial per-observation chain (one workgroup leads at a time)",
-                          "ms": obs_ms / args.steps, "us_per_ob": 1e3 * obs_ms / args.steps / max(P, 1)}
-        if loc:
-            # a localised sweep touches only the rows inside each ob's support: the dense flop count does not apply
-            out["roofline"]["launch_fp64_TFLOPs"] = None
-            out["roofline"]["launch_fp64_frac"] = None
-            out["roofline"]["kernel"] = "k_sweep_gc"
+        pa_kernel = {1: "k_pipe", 2: "k_diag+k_sweep", 3: "k_pipe_gram"}.get(kind, "?")
+        state_step_ms = state_ms / args.steps
+        obs_step_ms = obs_ms / args.steps
+        avg_launch_ms = state_ms / max(launches, 1)
+        launches_per_step = launches / float(args.steps)
+        obs_per_launch = n_active * args.steps / max(launches, 1)
+        # algorithmic bytes per assimilated ob = 16*N*(M+1) (per shard)
+        bytes_per_ob = 16.0 * rows * (M + 1)
+        # physical minimum of ONE state-sweep launch: read + write of the member block (and, in perturbation
+        # form, the mean); the fused transform / one-pass GC launches carry means in registers only
+        if loc == "GC":
+            kernel = "k_sweep_gc" if ctx.get_option("gc_onepass") else "k_sweep"
+            one_pass = bool(ctx.get_option("gc_onepass"))
+            phys_bytes = 16.0 * rows * M if one_pass else 16.0 * rows * (M + 1)
+        elif path_name == "transform":
+            kernel, phys_bytes = "k_transform", 16.0 * rows * M
+        else:
+            kernel, phys_bytes = "k_sweep", 16.0 * rows * (M + 1)
+        phys_gbps = phys_bytes / (avg_launch_ms * 1e-3) / 1e9
+        if loc == "GC":
+            pairs = float(ctx.get_option("gc_active_pairs"))            # (column, ob) pairs with taper != 0
+            flops_step = 4.0 * M * pairs * n_lead
+            bytes_touched = 16.0 * (M + 1) * pairs * n_lead             # SURVEY.md 8d, localised configs
+        elif path_name == "transform":
+            pairs, bytes_touched = None, None
+            flops_step = 2.0 * rows * M * (M + 1)
+        else:
+            pairs, bytes_touched = None, None
+            flops_step = 4.0 * rows * M * n_active
+        fp64_tflops = flops_step / (state_step_ms * 1e-3) / 1e12
+        dominant = pa_kernel if obs_step_ms > state_step_ms else kernel
+        out = {
+            "metric": "obs assimilated/sec on cov+update (EnSRF cycle, %d state x %d members x %d obs)"
+                      % (rows_g if strong else rows, M, P),
+            "value": value, "unit": "obs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None,
+            "dtype": "f64", "data": "synthetic",
+            "config": {"workload": wl["desc"], "rows_per_gpu": rows, "rows_global": rows_g, "members": M, "obs": P,
+                       "loc": loc or "none", "path": path_name, "obs_batch": ctx.get_option("obs_batch"),
+                       "phase_a": {1: "pipeline", 2: "per-batch", 3: "pipeline-gram"}.get(kind, "?"),
+                       "sharding": "one global grid split by (y,x) column over the ranks (ShardedEnSRF), obs block "
+                                   "replicated, one all-reduce of HX per cycle, no per-observation communication"},
+            # whole-cycle rates: algorithmic (effective, counts every ob's nominal pass) and physical
+            "GBps_algorithmic": bytes_per_ob * n_active * world / sec_per_step / 1e9,
+            "phase_ms": {"obs_phase": obs_step_ms, "state_phase": state_step_ms,
+                         "other": ms_per_step - obs_step_ms - state_step_ms},
+            # roofline of the state-sweep kernel (the cov+update sweep the metric names).  `achieved` / `frac` are
+            # PHYSICAL: the bytes one launch must move at minimum / its average duration (HIP events on the launch
+            # stream, inside the library) against the 8 TB/s spec.  The algorithmic figure of SURVEY.md 8d is
+            # `effective_GBps` (>> peak when one launch assimilates many obs).
+            "roofline": {"bound": "hbm", "kernel": kernel, "achieved": phys_gbps, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                         "frac": phys_gbps / HBM_PEAK_GBPS, "frac_of_copy_ceiling": phys_gbps / HBM_COPY_GBPS,
+                         "traffic": load_traffic(args.workload, "gc" if loc == "GC" else path_name),
+                         "bytes_per_launch_min": phys_bytes, "avg_launch_ms": avg_launch_ms,
+                         "launches_per_step": launches_per_step, "obs_per_launch": obs_per_launch,
+                         "effective_GBps": bytes_per_ob * obs_per_launch / (avg_launch_ms * 1e-3) / 1e9,
+                         "fp64_TFLOPs": fp64_tflops, "fp64_frac": fp64_tflops / FP64_PEAK_TFLOPS,
+                         "cycle_frac": phys_bytes * launches_per_step / sec_per_step / 1e9 / HBM_PEAK_GBPS,
+                         "dominant_kernel_by_time": dominant},
+            # Phase A (the serial chain): ~10 MB of HBM traffic per launch, bound by the step latency of ONE
+            # workgroup's chain, so neither roofline applies; reported as time and shader cycles per observation
+            "phase_a": {"kernel": pa_kernel,
+                        "bound": "latency of the serial per-observation chain (one workgroup leads at a time)",
+                        "ms": obs_step_ms, "us_per_ob": 1e3 * obs_step_ms / max(P, 1),
+                        "cycles_per_ob_at_2.4GHz": 2400.0 * (1e3 * obs_step_ms / max(P, 1)),
+                        "share_of_cycle": obs_step_ms / ms_per_step},
+        }
+        if loc == "GC":
+            out["roofline"]["active_column_ob_pairs"] = pairs
+            out["roofline"]["bytes_touched"] = bytes_touched
+            out["roofline"]["bytes_touched_GBps"] = bytes_touched / (state_step_ms * 1e-3) / 1e9
         if world == 1 and not args.no_cpu_baseline:
-            n_cpu_rows = min(args.cpu_rows, rows)
-            n_cpu_obs = min(args.cpu_obs + 1, P)
-            sample = X[:n_cpu_rows].cpu().numpy()
-            # sample obs: the first obs of the list, re-based onto sample rows so the loop is well-posed
-            srows = (pick[:n_cpu_obs] % n_cpu_rows)
-            s_hx = sample[srows]
-            s_val = s_hx.mean(axis=1) + 0.5
-            lk = None
             if loc == "GC":
-                raise SystemExit("cpu baseline for GC workloads: use --no-cpu-baseline")
-            out["cpu_baseline"] = cpu_baseline(sample, s_hx, s_val, err[:n_cpu_obs], rows, lk)
+                unit_rows, max_units = n_lead * nx_g, ny
+            else:
+                unit_rows, max_units = 1, rows
+
+            def fetch_sample(units, nobs):
+                if loc == "GC":
+                    ncs = units * nx_g                                   # the first `units` latitude circles
+                    Xs = torch.cat([X[l * ncol_l:l * ncol_l + ncs] for l in range(n_lead)]).cpu().numpy()
+                    rows_s = n_lead * ncs
+                    scol = pick[:nobs] % ncs
+                    srow = (pick[:nobs] // ncol_g) % n_lead * ncs + scol
+                    lk = dict(ob_lat=glat[scol], ob_lon=glon[scol], hw=np.full(nobs, wl["radius_km"]),
+                              lat=lat2[:units], lon=lon2[:units], state_shape=(n_lead, 1, units, nx_g))
+                else:
+                    Xs = X[:units].cpu().numpy()
+                    rows_s = units
+                    srow = pick[:nobs] % units
+                    lk = None
+                s_hx = Xs[srow]
+                return Xs, s_hx, s_hx.mean(axis=1) + 0.5, np.ones(nobs), lk, rows_s
+
+            out["cpu_baseline"] = cpu_baseline(fetch_sample, rows, M, args.cpu_warm, min(args.cpu_obs, max(P - args.cpu_warm, 1)),
+                                               args.cpu_seconds, args.cpu_rows,
+                                               dict(unit_rows=unit_rows, max_units=max_units))
         print(json.dumps(out))
     if world > 1:
         dist.destroy_process_group()

@@ -35,23 +35,32 @@ class Assimilation(object):
     def inflate_state(self):
         """Inflate the prior as specified by `inflation` (assimilation.py:52-118).
 
-        As in the reference this is a separate step the caller invokes -- `update()` never calls
-        it (ensrf.py:33-151) -- and it changes `self.prior`: a float scales the ensemble
-        perturbations of every variable (assimilation.py:62-69); a dict maps variable names to
-        float factors (:103-113) or the dimension names 'validtime' / 'y' / 'x' to arrays of
-        per-index factors that are broadcast over the other dimensions (:82-100).  The file
-        form (:71-79, an xarray/netCDF dataset of factors) is not supported."""
+        Called by `format_prior_state()` -- and therefore by `EnSRF.update()` -- whenever
+        `inflation is not None` (assimilation.py:131-134, reached from ensrf.py:44); callable on
+        its own too.  It changes `self.prior`: a float scales the ensemble perturbations of every
+        variable IN PLACE, so the caller's state object is inflated as well (assimilation.py:62-69);
+        a dict maps variable names to float factors (in place, :103-113) or the dimension names
+        'validtime' / 'y' / 'x' to arrays of per-index factors that are broadcast over the other
+        dimensions (:82-100; there the reference rebinds `self.prior` to a new object and leaves
+        the caller's alone).  A second call is a no-op (:57-59).  The file form (:71-79, an
+        xarray/netCDF dataset of factors) is not supported: SURVEY.md 8(f4).
+
+        PARITY UNPINNED: the reference's inflation code needs a real xarray Dataset, which the
+        build image lacks, so no golden vector covers it; this follows the source text."""
         if self.is_inflated:
             print("State already inflated.  Skipping additional inflation.")
             return
         prior = self.prior
 
-        def scale_var(name, factor):
+        def scale_var(name, factor, inplace=True):
             v = prior.variables[name]
             mean = v.mean(axis=-1, keepdims=True)
             if self.verbose:
                 print(name, "BEFORE stdev:", np.mean(np.std(v, axis=-1), axis=None))
-            prior.variables[name] = np.ascontiguousarray((v - mean) * factor + mean)
+            if inplace:
+                v[...] = (v - mean) * factor + mean          # `variables[v][:] = ...`, assimilation.py:67,113
+            else:
+                prior.variables[name] = np.ascontiguousarray((v - mean) * factor + mean)
             if self.verbose:
                 print(name, "AFTER stdev:", np.mean(np.std(prior.variables[name], axis=-1), axis=None))
 
@@ -79,7 +88,7 @@ class Assimilation(object):
                     shape = [1, 1, 1, 1]
                     shape[axis] = v.shape[0]
                     for name in prior.vars():
-                        scale_var(name, v.reshape(shape))
+                        scale_var(name, v.reshape(shape), inplace=False)
                 else:
                     assert isinstance(v, (float, np.floating))  # assimilation.py:106
                     if k not in prior.variables:
@@ -113,7 +122,12 @@ class Assimilation(object):
 
     def format_prior_state(self):
         """Augmented (xbm, Xbp): state rows then one row per ob
-        (assimilation.py:120-154)."""
+        (assimilation.py:120-154).  Inflates the prior first when `inflation` is set
+        (assimilation.py:131-134)."""
+        if self.inflation is not None:
+            if self.verbose:
+                print("Inflating Prior State")
+            self.inflate_state()
         obmeans, obperts = self.compute_ob_priors()
         X = np.ascontiguousarray(self.prior.to_vect(), dtype=np.float64)
         N, M = X.shape

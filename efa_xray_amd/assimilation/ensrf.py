@@ -56,13 +56,17 @@ class EnSRF(Assimilation):
         assim = np.array([bool(ob.assimilate_this) for ob in obs], dtype=bool)
         lat = lon = hw = None
         if loc_mode == _lib.LOC_GC:
+            # the reference reads localize_radius only for obs it assimilates (ensrf.py:74-76 precedes :101)
             for k, ob in enumerate(obs):
-                if ob.localize_radius is None:
+                if ob.assimilate_this and ob.localize_radius is None:
                     raise ValueError("observation %d has localize_radius=None but loc='GC' "
                                      "(the reference raises TypeError in abs(None), observation.py:120)" % k)
+
+            # lat/lon of EVERY ob enter the obs-obs taper (ensrf.py:113), assimilated or not
             lat = np.array([float(ob.lat) for ob in obs], dtype=np.float64)
             lon = np.array([float(ob.lon) for ob in obs], dtype=np.float64)
-            hw = np.array([float(ob.localize_radius) for ob in obs], dtype=np.float64)
+            hw = np.array([float(ob.localize_radius) if ob.localize_radius is not None else np.nan
+                           for ob in obs], dtype=np.float64)
         return P, value, error, assim, lat, lon, hw
 
     def _configure(self, ctx):
@@ -76,11 +80,17 @@ class EnSRF(Assimilation):
     def update(self):
         if self.verbose:
             print("Beginning update sequence")
+        loc_mode = self._loc_mode()
+        P, value, error, assim, lat, lon, hw = self._ob_arrays(loc_mode)
+        # ensrf.py:44 -> format_prior_state: the inflation hook comes first (assimilation.py:131-134);
+        # it may rebind self.prior (per-dimension factors, assimilation.py:96)
+        if self.inflation is not None:
+            if self.verbose:
+                print("Inflating Prior State")
+            self.inflate_state()
         prior = self.prior
         N = prior.nstate()
         M = prior.nmems()
-        loc_mode = self._loc_mode()
-        P, value, error, assim, lat, lon, hw = self._ob_arrays(loc_mode)
 
         # forward operator, once per ob from the prior (assimilation.py:45-48)
         if self.verbose:

@@ -93,6 +93,7 @@ struct efa_ctx {
   long n_active = 0;
   bool have_transform = false;   // identity rows were carried: (T, w) valid
   std::vector<uint8_t> h_assim;  // host copy of ob_assim
+  std::vector<double> h_hw;      // host copy of ob_halfwidth_km, sanitised for unassimilated obs
   DevBuf Ye_rec, coef;           // [P][M], [P][4]
   DevBuf traj, tw_mat, status, dbg;  // pipeline: trajectory records, GC obs-obs taper, status words, stamps
   const double* ye_ptr = nullptr;  // where Phase B reads the recorded ye rows
@@ -103,7 +104,8 @@ struct efa_ctx {
   DevBuf Yw, ymw;  // obs block workspace [(P+M)][M], [(P+M)]
   // --- state phase workspaces ---------------------------------------------
   DevBuf W;           // taper table [nb][ncol]
-  DevBuf gc_cnt, gc_off, gc_idx, gc_wts;  // one-pass GC sweep: CSR active lists
+  DevBuf gc_cnt, gc_off, gc_idx, gc_wts, gc_pairs;  // one-pass GC sweep: CSR active lists
+  long gc_active_pairs = 0;  // (column, ob) pairs with a non-zero taper in the last one-pass sweep
   std::vector<int> h_cnt;
   std::vector<long> h_off;
   DevBuf glat, glon;  // grid lat/lon [ncol]
@@ -177,10 +179,19 @@ int obs_phase(efa_ctx* c, int M, long P, double* ym_dev, double* Yp_dev, const d
     return fail(EFA_ERR_INVALID, "null observation array");
   if (loc_mode == EFA_LOC_GC) {
     if (!ob_lat || !ob_lon || !ob_hw) return fail(EFA_ERR_INVALID, "GC localisation needs ob_lat/ob_lon/ob_halfwidth_km");
-    for (long k = 0; k < P; ++k)
+    // the reference reads localize_radius only for obs it assimilates (ensrf.py:74-76 comes before :101):
+    // an unassimilated ob may carry any radius; it is replaced by a harmless one before it goes to the device
+    c->h_hw.assign(ob_hw, ob_hw + P);
+    for (long k = 0; k < P; ++k) {
+      if (!ob_assim[k]) {
+        c->h_hw[k] = 1.0;
+        continue;
+      }
       if (!(ob_hw[k] == ob_hw[k]) || ob_hw[k] == 0.0)
         return fail(EFA_ERR_INVALID, "observation %ld: localize_radius must be a non-zero number for loc='GC' "
                     "(the reference raises in abs(None), observation.py:120)", k);
+    }
+    ob_hw = c->h_hw.data();
   }
   c->h_assim.assign(ob_assim, ob_assim + P);
   for (long k = 0; k < P; ++k) c->n_active += ob_assim[k] ? 1 : 0;
@@ -395,12 +406,18 @@ int state_gc_onepass(efa_ctx* c, long rows, const double* xm_in, const double* X
   const long nblk = gc_num_blocks(ncol);
   EFA_TRY(c->gc_cnt.reserve((size_t)nblk * sizeof(int)));
   EFA_TRY(c->gc_off.reserve((size_t)(nblk + 1) * sizeof(long)));
+  EFA_TRY(c->gc_pairs.reserve(sizeof(unsigned long long)));
+  EFA_HIP(hipMemsetAsync(c->gc_pairs.p, 0, sizeof(unsigned long long), s));
   EFA_HIP(launch_gc_count(ncol, P, c->glat.as<double>(), c->glon.as<double>(), c->ob_lat.as<double>(),
-                          c->ob_lon.as<double>(), c->ob_hw.as<double>(), c->coef.as<double>(), c->gc_cnt.as<int>(), s));
+                          c->ob_lon.as<double>(), c->ob_hw.as<double>(), c->coef.as<double>(), c->gc_cnt.as<int>(),
+                          c->gc_pairs.as<unsigned long long>(), s));
   c->h_cnt.resize((size_t)nblk);
   c->h_off.resize((size_t)nblk + 1);
+  unsigned long long h_pairs = 0;
   EFA_HIP(hipMemcpyAsync(c->h_cnt.data(), c->gc_cnt.p, (size_t)nblk * sizeof(int), hipMemcpyDeviceToHost, s));
+  EFA_HIP(hipMemcpyAsync(&h_pairs, c->gc_pairs.p, sizeof(h_pairs), hipMemcpyDeviceToHost, s));
   EFA_HIP(hipStreamSynchronize(s));
+  c->gc_active_pairs = (long)h_pairs;
   long nnz = 0;
   for (long b = 0; b < nblk; ++b) {
     c->h_off[b] = nnz;
@@ -591,7 +608,7 @@ int efa_ctx_destroy(efa_ctx* c) {
   if (c->stream) (void)hipStreamSynchronize(c->stream);
   DevBuf* bufs[] = {&c->Ye_rec, &c->coef, &c->ob_val, &c->ob_err, &c->ob_asm, &c->ob_lat, &c->ob_lon, &c->ob_hw,
                     &c->d_prior_mean, &c->d_prior_var, &c->d_post_mean, &c->d_post_var, &c->d_assimilated,
-                    &c->Yw, &c->ymw, &c->traj, &c->tw_mat, &c->status, &c->dbg, &c->W, &c->gc_cnt, &c->gc_off, &c->gc_idx, &c->gc_wts, &c->glat, &c->glon, &c->xm_ws, &c->h_xm, &c->h_Xp, &c->h_ym, &c->h_Yp};
+                    &c->Yw, &c->ymw, &c->traj, &c->tw_mat, &c->status, &c->dbg, &c->W, &c->gc_cnt, &c->gc_off, &c->gc_idx, &c->gc_wts, &c->gc_pairs, &c->glat, &c->glon, &c->xm_ws, &c->h_xm, &c->h_Xp, &c->h_ym, &c->h_Yp};
   for (DevBuf* b : bufs) b->release();
   for (int i = 0; i < 4; ++i)
     if (c->ev[i]) (void)hipEventDestroy(c->ev[i]);
@@ -646,6 +663,9 @@ int efa_ctx_get_option(efa_ctx* c, const char* key, long* value) {
   else if (!strcmp(key, "timing")) *value = c->timing;
   else if (!strcmp(key, "gram")) *value = c->use_gram;
   else if (!strcmp(key, "pipeline")) *value = c->use_pipeline;
+  else if (!strcmp(key, "gc_onepass")) *value = c->gc_onepass;
+  else if (!strcmp(key, "gc_active_pairs")) *value = c->gc_active_pairs;
+  else if (!strcmp(key, "spin_limit")) *value = c->spin_limit;
   else if (!strcmp(key, "phase_a_kind")) *value = c->phase_a_kind;
   else if (!strcmp(key, "pipe_dbg_addr")) *value = (long)reinterpret_cast<uintptr_t>(c->dbg.p);
   else if (!strcmp(key, "device")) *value = c->device;

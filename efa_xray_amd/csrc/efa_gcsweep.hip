@@ -37,7 +37,8 @@ __global__ __launch_bounds__(64 * kBuildWaves) void k_gc_build(long ncol, long n
                                                                const double* __restrict__ ob_hw,
                                                                const double* __restrict__ coef, int* __restrict__ cnt,
                                                                const long* __restrict__ off, int* __restrict__ idx,
-                                                               double* __restrict__ wts) {
+                                                               double* __restrict__ wts,
+                                                               unsigned long long* __restrict__ npairs) {
   const int lane = threadIdx.x & 63;
   const long b = (long)blockIdx.x * kBuildWaves + (threadIdx.x >> 6);
   if (b >= nblk) return;
@@ -53,6 +54,7 @@ __global__ __launch_bounds__(64 * kBuildWaves) void k_gc_build(long ncol, long n
     la_hi = fmax(la_hi, __shfl_xor(la_hi, m, 64));
   }
   long running = FILL ? off[b] : 0;
+  long pairs = 0;  // (column, observation) pairs with a non-zero taper: SURVEY.md 8d's bytes_touched
   for (long k0 = 0; k0 < P; k0 += 64) {
     // 64 observations at once, lane <-> observation: the great-circle distance to ANY column of the
     // block is at least R * (latitude gap to the block's range); beyond 2 x halfwidth the
@@ -85,6 +87,7 @@ __global__ __launch_bounds__(64 * kBuildWaves) void k_gc_build(long ncol, long n
       }
       const unsigned long long bal = __ballot(w != 0.0);
       if (bal == 0ull) continue;  // wave-uniform
+      pairs += __builtin_popcountll(bal);
       int before = 0, total = 0;
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
@@ -100,7 +103,10 @@ __global__ __launch_bounds__(64 * kBuildWaves) void k_gc_build(long ncol, long n
       running += total;
     }
   }
-  if (!FILL && lane == 0) cnt[b] = (int)running;
+  if (!FILL && lane == 0) {
+    cnt[b] = (int)running;
+    if (npairs) atomicAdd(npairs, (unsigned long long)pairs);
+  }
 }
 
 constexpr int kChunk = 32;  // active observations staged in LDS at a time
@@ -238,11 +244,12 @@ hipError_t gc_launch(const GcSweepArgs& a, hipStream_t s) {
 long gc_num_blocks(long ncol) { return (ncol + kBlkCols - 1) / kBlkCols; }
 
 hipError_t launch_gc_count(long ncol, long P, const double* glat, const double* glon, const double* ob_lat,
-                           const double* ob_lon, const double* ob_hw, const double* coef, int* cnt, hipStream_t s) {
+                           const double* ob_lon, const double* ob_hw, const double* coef, int* cnt, unsigned long long* npairs,
+                           hipStream_t s) {
   const long nblk = gc_num_blocks(ncol);
   if (nblk <= 0) return hipSuccess;
   hipLaunchKernelGGL((k_gc_build<false>), dim3((unsigned)((nblk + kBuildWaves - 1) / kBuildWaves)), dim3(64 * kBuildWaves), 0,
-                     s, ncol, nblk, P, glat, glon, ob_lat, ob_lon, ob_hw, coef, cnt, nullptr, nullptr, nullptr);
+                     s, ncol, nblk, P, glat, glon, ob_lat, ob_lon, ob_hw, coef, cnt, nullptr, nullptr, nullptr, npairs);
   return hipGetLastError();
 }
 
@@ -252,7 +259,7 @@ hipError_t launch_gc_fill(long ncol, long P, const double* glat, const double* g
   const long nblk = gc_num_blocks(ncol);
   if (nblk <= 0) return hipSuccess;
   hipLaunchKernelGGL((k_gc_build<true>), dim3((unsigned)((nblk + kBuildWaves - 1) / kBuildWaves)), dim3(64 * kBuildWaves), 0,
-                     s, ncol, nblk, P, glat, glon, ob_lat, ob_lon, ob_hw, coef, nullptr, off, idx, wts);
+                     s, ncol, nblk, P, glat, glon, ob_lat, ob_lon, ob_hw, coef, nullptr, off, idx, wts, nullptr);
   return hipGetLastError();
 }
 

@@ -133,7 +133,8 @@ struct GcSweepArgs {
 };
 long gc_num_blocks(long ncol);
 hipError_t launch_gc_count(long ncol, long P, const double* glat, const double* glon, const double* ob_lat,
-                           const double* ob_lon, const double* ob_hw, const double* coef, int* cnt, hipStream_t s);
+                           const double* ob_lon, const double* ob_hw, const double* coef, int* cnt, unsigned long long* npairs,
+                           hipStream_t s);
 hipError_t launch_gc_fill(long ncol, long P, const double* glat, const double* glon, const double* ob_lat,
                           const double* ob_lon, const double* ob_hw, const double* coef, const long* off, int* idx,
                           double* wts, hipStream_t s);

@@ -14,7 +14,7 @@ identical obs block, runs Phase A redundantly and sweeps only its own rows.
 There is no per-observation communication.  With `torch.distributed` backend
 "nccl" the all-reduce is RCCL over xGMI.
 
-The arithmetic is delegated to an *engine* with the five methods of
+The arithmetic is delegated to an *engine* with the methods of
 `HipEngine`; the product engine is the HIP library.  (Tests drive the same host
 logic on CPU ranks with gloo by passing their own engine.)
 """
@@ -71,6 +71,12 @@ class HipEngine(object):
     def form_perts(self, rows, M, X, xm, Xp):
         self.ctx.form_perts(rows, M, X.data_ptr(), xm.data_ptr(), Xp.data_ptr())
 
+    def inflate(self, rows, M, X, factor):
+        """X <- mean + factor * (X - mean), in place on the resident shard (assimilation.py:62-69)."""
+        xm = self.empty((max(rows, 1),))
+        self.ctx.form_perts(rows, M, X.data_ptr(), xm.data_ptr(), X.data_ptr(), scale=factor)
+        self.ctx.posterior(rows, M, xm.data_ptr(), X.data_ptr(), X.data_ptr())
+
     def obs_phase(self, M, P, ym, Yp, ob):
         return self.ctx.obs_phase(M, P, ym.data_ptr(), Yp.data_ptr(), ob["value"], ob["error"], ob["assim"],
                                   _lib.LOC_GC if ob.get("loc") == "GC" else _lib.LOC_NONE,
@@ -106,14 +112,27 @@ class ShardedEnSRF(object):
             dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group)
         return t
 
-    def update(self, X_local, post_local, sten_idx, sten_wts, ob, grid_lat=None, grid_lon=None):
+    def partial_estimates(self, X_local, sten_idx, sten_wts, inflation=None):
+        """Stage 1: this shard's contribution to the obs-space prior ensemble HX (P x M): the
+        stencil points it owns, zeros elsewhere.  `inflation` (a float) first inflates the
+        resident shard in place about its ensemble mean -- the constant form of
+        `Assimilation.inflate_state` (assimilation.py:62-69), which the reference applies
+        before the obs priors are computed (assimilation.py:131-138)."""
         eng, M = self.engine, self.M
+        if inflation is not None:
+            eng.inflate(self.rows_local, M, X_local, float(inflation))
         P = int(np.asarray(sten_idx).shape[0])
         lidx, lwts = localize_stencil(sten_idx, sten_wts, self.n_lead, self.ncol, self.lo, self.hi)
         HX = eng.empty((P, M))
+        eng.forward_stencil(self.rows_local, M, X_local, lidx, lwts, HX)
+        return HX
+
+    def assimilate(self, X_local, post_local, HX, ob, grid_lat=None, grid_lon=None):
+        """Stage 2, after HX has been summed over the shards: obs-space priors, Phase A
+        (replicated: identical on every rank) and the sweep of this shard's rows."""
+        eng, M = self.engine, self.M
+        P = int(HX.shape[0])
         ym = eng.empty((max(P, 1),))
-        eng.forward_stencil(self.rows_local, M, X_local, lidx, lwts, HX)   # partial estimates
-        self.all_reduce_sum(HX)                                            # the one exchange step
         eng.form_perts(P, M, HX, ym, HX)                                   # assimilation.py:46-48
         diag = eng.obs_phase(M, P, ym, HX, ob)                             # identical on every rank
         glat = glon = None
@@ -122,3 +141,8 @@ class ShardedEnSRF(object):
             glon = np.ascontiguousarray(np.asarray(grid_lon, dtype=np.float64).reshape(-1)[self.lo:self.hi])
         eng.state_cycle(self.rows_local, M, X_local, post_local, glat, glon, self.n_lead)
         return diag
+
+    def update(self, X_local, post_local, sten_idx, sten_wts, ob, grid_lat=None, grid_lon=None, inflation=None):
+        HX = self.partial_estimates(X_local, sten_idx, sten_wts, inflation)
+        self.all_reduce_sum(HX)                                            # the one exchange step
+        return self.assimilate(X_local, post_local, HX, ob, grid_lat, grid_lon)

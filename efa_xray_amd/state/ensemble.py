@@ -278,8 +278,21 @@ class EnsembleState(object):
             print("Interpolation is outside of time range in state!")
             return None
         rows, wts = st
-        vect = self.to_vect()
-        return (wts[:, None] * vect[rows]).sum(axis=0)
+        return self.gather_rows(rows, wts)
+
+    def gather_rows(self, rows, wts):
+        """sum_j wts[j] * to_vect()[rows[j]] without forming to_vect(): the
+        reference gathers `variables[var][:, closey, closex, :]` the same way
+        (ensemble.py:227-236)."""
+        nt, ny, nx = self.ntimes(), self.ny(), self.nx()
+        names = self.vars()
+        out = np.zeros(self.nmems())
+        for r, w in zip(np.asarray(rows, dtype=np.int64), wts):
+            iv, rem = divmod(int(r), nt * ny * nx)
+            it, rem = divmod(rem, ny * nx)
+            y, x = divmod(rem, nx)
+            out += w * self.variables[names[iv]][it, y, x, :]
+        return out
 
     # -- persistence (ensemble.py:269-273) ---------------------------------------
     def save_to_disk(self, filename="ens_state.nc"):

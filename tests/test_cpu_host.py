@@ -169,16 +169,19 @@ def test_obs_statistics_table_columns():
     assert df2['post mean'][1] == 0.5 and df2['post variance'][0] == 2.5
 
 
-def test_inflate_state_float_dict_and_not_applied_by_update_helpers():
-    """assimilation.py:52-118: inflation is a separate step on the prior; float / per-variable /
-    per-dimension forms.  (No GPU needed: it is host logic on the NumPy-backed state.)"""
+def test_inflate_state_float_dict_forms():
+    """assimilation.py:52-118: float / per-variable / per-dimension forms of inflate_state().
+    (No GPU needed: it is host logic on the NumPy-backed state.)  PARITY UNPINNED: the reference's
+    inflation needs a real xarray Dataset, absent from the image; this follows its source text."""
     from efa_xray_amd.assimilation.assimilation import Assimilation
     st, arr, lat, lon = _state(7)
     nvar, nt, ny, nx, nm = arr.shape
-    a = Assimilation(__import__("copy").deepcopy(st), [], inflation=1.3, verbose=False)
+    mine = __import__("copy").deepcopy(st)
+    a = Assimilation(mine, [], inflation=1.3, verbose=False)
     assert a.is_inflated is False
     a.inflate_state()
     assert a.is_inflated is True
+    assert a.prior is mine                  # the float form works in place on the caller's state (assimilation.py:67)
     for i in range(nvar):
         assert np.allclose(a.prior.variables["v%d" % i].reshape(-1, nm),
                            orc.inflate_constant(arr[i].reshape(-1, nm), 1.3), rtol=1e-14, atol=1e-14)
@@ -202,3 +205,33 @@ def test_inflate_state_float_dict_and_not_applied_by_update_helpers():
         assert np.allclose(c.prior.variables["v%d" % i], (arr[i] - m) * f[:, None, None, None] + m, rtol=1e-14, atol=1e-14)
     with pytest.raises(NotImplementedError):
         Assimilation(mine, [], inflation="factors.nc", verbose=False).inflate_state()
+
+
+def test_inflation_hook_runs_inside_format_prior_state_and_update():
+    """assimilation.py:131-134 (reached from ensrf.py:44): `format_prior_state()` -- and so `update()` --
+    inflates the prior first whenever `inflation is not None`.  The GPU work after the hook is cut
+    off here by a sentinel; tests/test_gpu_parity.py checks the numbers."""
+    from efa_xray_amd import EnSRF
+    from efa_xray_amd.assimilation.assimilation import Assimilation
+
+    class Stop(Exception):
+        pass
+
+    def stop(self):
+        raise Stop()
+
+    st, arr, lat, lon = _state(9)
+    nm = arr.shape[-1]
+    for cls, call, kw in ((Assimilation, "format_prior_state", {}), (EnSRF, "update", {}), (EnSRF, "format_prior_state", {})):
+        mine = __import__("copy").deepcopy(st)
+        a = cls(mine, [], inflation=1.25, verbose=False, **kw)
+        a.compute_ob_estimates = stop.__get__(a)
+        with pytest.raises(Stop):
+            getattr(a, call)()
+        assert a.is_inflated is True
+        assert np.allclose(mine.to_vect(), orc.inflate_constant(st.to_vect(), 1.25), rtol=1e-14, atol=1e-14)
+        none = cls(__import__("copy").deepcopy(st), [], inflation=None, verbose=False)
+        none.compute_ob_estimates = stop.__get__(none)
+        with pytest.raises(Stop):
+            getattr(none, call)()
+        assert none.is_inflated is False and np.array_equal(none.prior.to_vect(), st.to_vect())

@@ -1,0 +1,142 @@
+"""GPU tests of the Python API either side of the loop: the inflation hook of
+`format_prior_state` (assimilation.py:131-134), the per-ob statistics table fed from the kernel's
+diagnostics (postprocess.py:8-39), radius validation limited to assimilated obs (ensrf.py:74-76
+precedes :101) and the default forward operator built on the device (ensemble.py:152-239)."""
+from copy import deepcopy
+
+import numpy as np
+import pytest
+
+from oracle import ensrf_oracle as orc
+from test_gpu_parity import assert_parity, RTOL
+
+pytestmark = pytest.mark.gpu
+
+
+def _state_and_obs(seed, loc, P=40, M=20, nvar=2, nt=1, ny=12, nx=16):
+    from efa_xray_amd import EnsembleState, Observation
+    rng = np.random.default_rng(seed)
+    lat, lon = np.meshgrid(np.linspace(20, 60, ny), np.linspace(200, 280, nx), indexing="ij")
+    arr = rng.standard_normal((nvar, nt, ny, nx, 1)) + 3.0 * rng.standard_normal((nvar, nt, ny, nx, M))
+    state = EnsembleState.from_array(arr, lat, lon)
+    N = state.nstate()
+    rows = rng.choice(N, P, replace=False)
+
+    class RowOb(Observation):
+        def estimate(self, st):
+            return st.to_vect()[self.row].copy()
+
+    X = state.to_vect().copy()
+    obs = []
+    for k in range(P):
+        col = rows[k] % (ny * nx)
+        ob = RowOb(value=float(X[rows[k]].mean() + rng.standard_normal()), error=float(rng.uniform(0.5, 1.5)),
+                   lat=float(lat.reshape(-1)[col]), lon=float(lon.reshape(-1)[col]), obtype="var0", time=0,
+                   assimilate_this=(k % 7 != 3), localize_radius=1500.0, description="ob%d" % k)
+        ob.row = int(rows[k])
+        obs.append(ob)
+    kw = {}
+    if loc == "GC":
+        kw = dict(loc="GC", ob_lat=[o.lat for o in obs], ob_lon=[o.lon for o in obs],
+                  ob_halfwidth=[o.localize_radius for o in obs], grid_lat=lat, grid_lon=lon,
+                  state_shape=(nvar, nt, ny, nx))
+    return state, obs, X, rows, kw
+
+
+def _oracle_cycle(X, rows, obs, kw):
+    return orc.ensrf_cycle(X, X[rows], np.array([o.value for o in obs]), np.array([o.error for o in obs]),
+                           np.array([o.assimilate_this for o in obs]), **kw)
+
+
+@pytest.mark.parametrize("loc", [False, "GC"])
+def test_update_applies_float_inflation_like_format_prior_state(loc):
+    """`EnSRF(state, obs, inflation=1.3).update()` == the oracle cycle on `inflate_constant(X, 1.3)`
+    (assimilation.py:131-134 inside format_prior_state, reached from ensrf.py:44; float branch :62-69,
+    in place on the caller's state).  PARITY UNPINNED: the reference's inflation branch needs a real
+    xarray Dataset (absent from the image), so no golden covers it; this follows the source text."""
+    from efa_xray_amd import EnSRF
+    state, obs, X, rows, kw = _state_and_obs(3, loc)
+    flt = EnSRF(state, obs, inflation=1.3, verbose=False, loc=loc)
+    post_state, obs_out = flt.update()
+    Xi = orc.inflate_constant(X, 1.3)
+    assert flt.is_inflated
+    assert_parity(state.to_vect(), Xi, "the caller's state is inflated in place (assimilation.py:67)")
+    ref_post, _, _, diag = _oracle_cycle(Xi, rows, obs, kw)
+    assert_parity(post_state.to_vect(), ref_post, "post (inflation=1.3)")
+    assert_parity([o.prior_var for o in obs_out], diag["prior_var"], "prior_var")
+    got = np.array([o.post_mean for o in obs_out if o.assimilated], dtype=float)
+    assert_parity(got, diag["post_mean"][diag["assimilated"]], "post_mean")
+    # a second update() on the same filter object does not inflate again (assimilation.py:57-59)
+    before = state.to_vect().copy()
+    flt.update()
+    assert np.array_equal(state.to_vect(), before)
+    # and the (xbm, Xbp) helper pair goes through the same hook
+    state2, obs2, X2, rows2, kw2 = _state_and_obs(3, loc)
+    f2 = EnSRF(state2, obs2, inflation=1.3, verbose=False, loc=loc)
+    xbm, Xbp = f2.format_prior_state()
+    r_xbm, r_Xbp = orc.format_prior_state(Xi, Xi[rows])
+    assert_parity(xbm, r_xbm, "xbm of the inflated prior")
+    assert_parity(Xbp, r_Xbp, "Xbp of the inflated prior")
+
+
+def test_update_with_per_variable_and_per_dimension_inflation():
+    from efa_xray_amd import EnSRF
+    state, obs, X, rows, kw = _state_and_obs(4, False, nt=3)
+    nvar, nt, ny, nx, M = state.shape()
+    f = np.linspace(1.0, 1.4, nt)
+    mine = deepcopy(state)
+    post_state, _ = EnSRF(mine, obs, inflation={"validtime": f}, verbose=False).update()
+    assert np.array_equal(mine.to_vect(), X), "per-dimension factors leave the caller's state alone (assimilation.py:96)"
+    arr = X.reshape(nvar, nt, ny, nx, M)
+    m = arr.mean(axis=-1, keepdims=True)
+    Xi = ((arr - m) * f[None, :, None, None, None] + m).reshape(-1, M)
+    ref_post, _, _, _ = _oracle_cycle(Xi, rows, obs, kw)
+    assert_parity(post_state.to_vect(), ref_post, "post (per-time inflation)")
+
+
+@pytest.mark.parametrize("loc", [False, "GC"])
+def test_statistics_table_from_kernel_diagnostics(loc):
+    """f3: `obs_assimilation_statistics(prior, post, obs, from_diagnostics=True)` after a real `update()` equals
+    the table built from the oracle's diagnostics; the reference's re-interpolating form (postprocess.py:24-31)
+    is evaluated too and agrees on the prior columns."""
+    from efa_xray_amd import EnSRF
+    from efa_xray_amd.postprocess.postprocess import obs_assimilation_statistics
+    state, obs, X, rows, kw = _state_and_obs(8, loc)
+    post_state, obs_out = EnSRF(state, obs, verbose=False, loc=loc).update()
+    _, _, _, diag = _oracle_cycle(X, rows, obs, kw)
+    df = obs_assimilation_statistics(state, post_state, obs_out, from_diagnostics=True)
+    assert len(df) == len(obs)
+    assert_parity(np.asarray(df["prior mean"], dtype=float), diag["prior_mean"], "prior mean column")
+    assert_parity(np.asarray(df["prior variance"], dtype=float), diag["prior_var"], "prior variance column")
+    a = diag["assimilated"]
+    assert np.array_equal(np.asarray(df["assimilated"], dtype=bool), a)
+    assert_parity(np.asarray(df["post mean"], dtype=float)[a], diag["post_mean"][a], "post mean column")
+    assert_parity(np.asarray(df["post variance"], dtype=float)[a], diag["post_var"][a], "post variance column")
+    # unassimilated obs report their prior as their posterior
+    assert_parity(np.asarray(df["post mean"], dtype=float)[~a], diag["prior_mean"][~a], "post mean of unassimilated obs")
+    assert list(df["lat"]) == [o.lat for o in obs] and list(df["description"]) == [o.description for o in obs]
+    # the reference's form: re-estimate on prior and posterior states
+    df2 = obs_assimilation_statistics(state, post_state, obs_out)
+    # prior mean of ob k in the table is the mean of the UNTOUCHED prior (not the running one)
+    assert_parity(np.asarray(df2["prior mean"], dtype=float), X[rows].mean(axis=1), "re-interpolated prior mean")
+    if not loc:
+        # without localisation the last assimilated ob's row is final when it is assimilated
+        k = int(np.nonzero(a)[0][-1])
+        assert abs(df2["post mean"][k] - diag["post_mean"][k]) <= RTOL * max(1.0, abs(diag["post_mean"][k]))
+
+
+def test_unassimilated_obs_may_lack_a_localize_radius():
+    """ensrf.py:74-76 skips an unassimilated ob before its radius is ever read (:101)."""
+    from efa_xray_amd import EnSRF
+    state, obs, X, rows, kw = _state_and_obs(12, "GC")
+    for k, o in enumerate(obs):
+        if not o.assimilate_this:
+            o.localize_radius = None if k % 2 else 0.0
+    post_state, obs_out = EnSRF(state, obs, verbose=False, loc="GC").update()
+    kw["ob_halfwidth"] = [o.localize_radius if o.assimilate_this else 1.0 for o in obs]
+    ref_post, _, _, diag = _oracle_cycle(X, rows, obs, kw)
+    assert_parity(post_state.to_vect(), ref_post, "post")
+    assert_parity([o.prior_var for o in obs_out], diag["prior_var"], "prior_var")
+    obs[0].assimilate_this, obs[0].localize_radius = True, None
+    with pytest.raises(ValueError):
+        EnSRF(state, obs, verbose=False, loc="GC").update()
