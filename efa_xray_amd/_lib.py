@@ -106,7 +106,8 @@ def load_library(path=None):
     global _lib
     if _lib is not None and path is None:
         return _lib
-    p = path or LIB_PATH
+    # EFA_HIP_LIB: a diagnostic build of the same library (tools/ only; `make -C efa_xray_amd/csrc diag`)
+    p = path or os.environ.get("EFA_HIP_LIB") or LIB_PATH
     if not os.path.exists(p):
         raise RuntimeError(
             "libefa_hip.so not found at %s: the HIP extension is not built "

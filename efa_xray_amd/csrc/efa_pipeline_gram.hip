@@ -48,6 +48,7 @@ constexpr int kRowsWG = kPipeRowsPerWG;  // 64
 static_assert(PLg == 4 && kRowsWG == 64, "layout assumptions of the Gram kernel");
 
 enum { cReady = 0, cBail = 1, cSReady = 2, cFwd = 3, cProg = 4, cHProg = 8 };
+constexpr int kScStride = 8;  // doubles per step in the pivot's scalar records
 
 __device__ __forceinline__ u64 g_traj_load(const u64* p) {
   return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -112,7 +113,7 @@ __global__ __launch_bounds__(kGT) void k_pipe_gram(const PipeArgs a) {
   // per-step records of the pivot wave (every LDS instruction on that wave costs the chain ~30 cycles of
   // issue, so a step publishes as little as possible): one b128 per lane and two by lane 0
   double2* s_gk = reinterpret_cast<double2*>(U);  // [step][row] = {G_kj, kb_j}
-  double* s_sc = U + 2 * kRowsWG * kRowsWG;       // [step][4]   = innov, rden, beta, active
+  double* s_sc = U + 2 * kRowsWG * kRowsWG;       // [step][8]   = innov, rden, beta, active, prior mean, prior var
 
   const int tid = threadIdx.x;
   // wave roles: 0-3 vector, 4 pivot, 5-6 helpers, 7 loader (pairing the pivot with the loader on one SIMD
@@ -309,7 +310,8 @@ __global__ __launch_bounds__(kGT) void k_pipe_gram(const PipeArgs a) {
           break;
         }
         const double* slot = ring + (size_t)(f % kRingG) * TS;
-        const double* sc = s_sc + (size_t)(f - own0) * 4;
+        const int st = (int)(f - own0);
+        const double* sc = s_sc + (size_t)st * kScStride;
         u64* rec = a.traj + (size_t)f * TS;
 #pragma unroll
         for (int e = 0; e < EPL; ++e) {
@@ -318,6 +320,33 @@ __global__ __launch_bounds__(kGT) void k_pipe_gram(const PipeArgs a) {
           if (idx < TS) g_traj_store(rec + idx, idx < PAD ? slot[idx] : ((si >= 0 && si < 4) ? sc[si] : 0.0));
         }
         if (lane == 0) g_ctl_set(&ctl[cFwd], (int)f);
+        // the ob's diagnostics and sweep coefficients, derived from the pivot's record (the pivot wave itself
+        // keeps nothing per ob: every instruction there is on the chain).  The same operations in the same
+        // order as the pivot's own lane k: km = kc rden with kc = G_kk/(M-1) (x the taper of an ob with itself,
+        // exactly 1), and the ob's own row is scaled by (1 - kb_k)  (:144-149).
+        if (lane == 0) {
+          const double2 s01 = *reinterpret_cast<const double2*>(sc);      // innov, rden
+          const double2 s23 = *reinterpret_cast<const double2*>(sc + 2);  // beta, active
+          const double2 s45 = *reinterpret_cast<const double2*>(sc + 4);  // prior mean, prior var
+          const double2 gk = s_gk[st * kRowsWG + st];                     // G_kk, kb_k
+          const bool act = s23.y != 0.0;
+          a.prior_mean[f] = s45.x;                                        // :66
+          a.prior_var[f] = s45.y;                                         // :70
+          double* ck = a.coef + (size_t)f * kCoefStride;
+          ck[0] = act ? s01.x : 0.0;
+          ck[1] = act ? s01.y : 0.0;
+          ck[2] = act ? s23.x : 0.0;
+          ck[3] = act ? 1.0 : 0.0;
+          a.assimilated[f] = act ? 1 : 0;                                 // :74-76, :149
+          if (act) {
+            double kc = gk.x * rM1;                                       // :95 (taper of the ob with itself: 1)
+            if (a.loc_mode != 0) kc = tw_s[st * kRowsWG + st] * kc;       // :115
+            const double km = kc * s01.y;                                 // :119
+            const double fsc = 1.0 - gk.y;
+            a.post_mean[f] = s45.x + km * s01.x;                          // :130
+            a.post_var[f] = (fsc * fsc) * s45.y;
+          }
+        }
         EFA_GSTAMP(lane == 0, f, 7);
       }
       EFA_BLOCKSTAMP(lane == 0, 2);
@@ -349,34 +378,26 @@ __global__ __launch_bounds__(kGT) void k_pipe_gram(const PipeArgs a) {
     if (wave == kVW) {
       // ---------------- pivot wave: lane j <-> row j of the workgroup ----------------
       // The loop below is the serial chain of the whole filter, and one wave issues in order: every
-      // instruction in it costs issue slots, so per-step work is kept to the recurrence itself.
-      // Per-ob constants come from LDS with uniform addresses, an ob's diagnostics stay in its lane, and the gain factors are arranged for a short dependent chain:
+      // instruction in it costs issue slots, so per-step work is kept to the recurrence itself.  The gain
+      // factors are arranged for a short dependent chain:
       //   kdenom -> q0 = rsq(kdenom) -> { Newton step of q  ||  beta0 = 1/(1 + sqrt(err) q0) } -> beta
       // with beta = beta0 - beta0^2 sqrt(err) q0 d for q = q0 (1 + d)  (d ~ 1e-8: the d^2 term is < 1 ulp).
-      const long obj = own0 + lane;
-      const bool is_ob = lane < nb;
       double mu = pm[lane], xmv = pm[kRowsWG + lane];
       const bool my_asm = pre_asm;
-      pv[lane] = pre_val;
-      pv[kRowsWG + lane] = pre_err;
-      pv[2 * kRowsWG + lane] = pre_sq;
+      const double err_l = pre_err, sq_l = pre_sq, val_l = pre_val;   // this lane's ob constants: fetched by v_readlane
       const u64 asm_mask = __ballot(my_asm);
-      // cancellation guard: an assimilated pivot whose G_kk fell below 1e-3 of its value at block start
+      // cancellation guard: an assimilated pivot whose G_kk fell below 1e-3 of its value at block start.  It is
+      // only ACCUMULATED in the loop (one compare + two scalar ops per step) and acted upon after the block: a
+      // tripped guard abandons the whole launch, so the numbers produced meanwhile are never used.
       const double thr = my_asm ? 1e-3 * G_s[lane * kRowsWG + lane] : -1.0;
+      u64 bad = 0ull;
       bool bailed = false;
-      double o_pm = 0.0, o_pv = 0.0, o_in = 0.0, o_rd = 0.0, o_be = 0.0, o_km = 0.0;
+#ifdef EFA_PIPE_BLOCKTIME
+      int slow_rows = 0;  // steps whose hand-over row was late
+#endif
       double g = G_s[lane];             // row 0
       double g1 = G_s[kRowsWG + lane];  // row 1
-      // per-ob constants (and the taper row) are fetched one step ahead: an LDS round trip at the top of a
-      // step would sit on the chain
-      struct Pre {
-        double val, err, sq, tw;
-      };
       const bool gc = a.loc_mode != 0;
-      const double* twp = gc ? tw_s + lane : pv + lane;  // always a valid address: the load is unconditional
-      // two register sets used alternately (the loop is unrolled by two): with one set the compiler copies
-      // "next" into "current" at the back edge and, for that, drains the whole LDS queue every step
-      Pre pa{pv[0], pv[kRowsWG], pv[2 * kRowsWG], twp[0]}, pb{0.0, 1.0, 1.0, 1.0};
       // slow path of the hand-over (the helper is late): poll flag and row together
       auto wait_row = [&](int kk, double& r2) {
         const int* flag = &ctl[cHProg + (kk & 1)];
@@ -396,16 +417,14 @@ __global__ __launch_bounds__(kGT) void k_pipe_gram(const PipeArgs a) {
       };
       // One step of the recurrence.  has1 / has2: rows kk+1 / kk+2 exist; poll: row kk+2 comes from a
       // helper (kk >= 1).  The block loop below calls it with constants, so the steady-state body is
-      // straight-line code: a taken branch costs this wave more than a dozen arithmetic instructions.
-      auto pivot_step = [&](const int kk, const bool has1, const bool has2, const bool poll, const Pre& cur, Pre& nxt) {
-        const double valk = cur.val, errk = cur.err, sqk = cur.sq, twk = cur.tw;
-        {
-          const int kn = (kk + 1 < kRowsWG) ? kk + 1 : kk;
-          nxt.val = pv[kn];
-          nxt.err = pv[kRowsWG + kn];
-          nxt.sq = pv[2 * kRowsWG + kn];
-          nxt.tw = twp[gc ? kn * kRowsWG : 0];
-        }
+      // straight-line code.  What one step costs this wave is its INSTRUCTION COUNT (one wave issues in order,
+      // an LDS instruction costs it 15-35 cycles, a taken branch a dozen arithmetic instructions), so:
+      //   - per-ob constants live in the ob's lane and are fetched with v_readlane (no LDS read, no latency);
+      //   - the ob's diagnostics are not kept here: the forwarder wave derives them from the step's record;
+      //   - the record is published at the END of the step, after the hand-over row has been consumed, so the
+      //     wait for that row never has the record's own stores in front of it.
+      auto pivot_step = [&](const int kk, const bool has1, const bool has2, const bool poll, auto gc_tag) {
+        constexpr bool GC = decltype(gc_tag)::value;  // compile-time: a run-time test costs the chain a taken branch per step
         // row kk+2 from its helper, read speculatively (flag first, then the row): the helper puts the
         // row a pivot needs next into G_s before anything else, right after the previous record appears,
         // so it is normally there by now and the round trip is hidden behind the whole gain chain
@@ -415,12 +434,11 @@ __global__ __launch_bounds__(kGT) void k_pipe_gram(const PipeArgs a) {
           f_early = poll ? g_ctl_lane(&ctl[cHProg + (kk & 1)]) : 0;
           r2 = G_s[(kk + 2) * kRowsWG + lane];
         }
+        const double twk = GC ? tw_s[kk * kRowsWG + lane] : 1.0;       // consumed after the gain chain
         const bool act = ((asm_mask >> kk) & 1) != 0;
-        if (__builtin_expect(((__ballot(!(g > thr)) >> kk) & 1) != 0 && !EFA_EXP(0x70), 0)) {  // the downdate may have cancelled
-          if (lane == 0) give_up();
-          return false;
-        }
+        if (!EFA_EXP(0x70)) bad |= __ballot(!(g > thr)) & (1ull << kk);
         const double Gkk = rl(g, kk), muk = rl(mu, kk), xmk = rl(xmv, kk);
+        const double errk = rl(err_l, kk), sqk = rl(sq_l, kk), valk = rl(val_l, kk);
         const double mu2 = muk * muk;
         const double kdenom = __builtin_fma(Gkk, invM, errk - mu2);   // var + err  (:69, :91)
         const double q0 = __builtin_amdgcn_rsq(kdenom);
@@ -435,27 +453,14 @@ __global__ __launch_bounds__(kGT) void k_pipe_gram(const PipeArgs a) {
         const double beta0 = __builtin_fma(r0, __builtin_fma(eb, eb, eb), r0);
         const double beta = __builtin_fma(-((beta0 * beta0) * sq0), d, beta0);  // 1 / (1 + sqrt(err / kdenom))  (:135)
         double kc = g * rM1;                                          // :95
-        kc = (gc ? twk : 1.0) * kc;                                   // :115
+        if (GC) kc = twk * kc;                                        // :115
         const double km = act ? kc * rden : 0.0;                      // :119
         const double kb = beta * km;                                  // :136
         const double innov = valk - xmk;                              // :85
-        s_gk[kk * kRowsWG + lane] = make_double2(g, kb);
-        if (lane == 0) {
-          double2* sc = reinterpret_cast<double2*>(s_sc + (size_t)kk * 4);
-          sc[0] = make_double2(innov, rden);
-          sc[1] = make_double2(beta, act ? 1.0 : 0.0);
-          g_ctl_set(&ctl[cSReady], kk + 1);
-        }
-        if (lane == kk) {  // this ob's diagnostics stay in its lane
-          o_pm = xmk;                                  // :66
-          o_pv = __builtin_fma(Gkk, invM, -mu2);       // np.var, ddof = 0 (:69, :70)
-          o_in = innov;
-          o_rd = rden;
-          o_be = beta;
-          o_km = km;
-        }
+        const double gpub = g;
         xmv = xmv + km * innov;                                       // :130
         mu = __builtin_fma(-kb, muk, mu);
+        bool ok = true;
         if (has1) {
           // g1 = row kk+1 through step kk-1; row kk+2 through step kk-1 comes from its helper (handed
           // over through G_s during the helper's step kk-1)
@@ -463,15 +468,29 @@ __global__ __launch_bounds__(kGT) void k_pipe_gram(const PipeArgs a) {
           const double gi = rl(g, kk + 1), ai = rl(kb, kk + 1);
           const double gnew = __builtin_fma(-ai, t, __builtin_fma(-kb, gi, g1));
           if (has2) {
-            if (__builtin_expect(poll && __builtin_amdgcn_readfirstlane(f_early) < kk + 2, 0)) {
-              if (!wait_row(kk, r2)) return false;
+            if (__builtin_expect(poll && !EFA_EXP(2048) && __builtin_amdgcn_readfirstlane(f_early) < kk + 2, 0)) {
+#ifdef EFA_PIPE_BLOCKTIME
+              ++slow_rows;
+#endif
+              ok = wait_row(kk, r2);
             }
             const double gi2 = rl(g, kk + 2), ai2 = rl(kb, kk + 2);
             g1 = __builtin_fma(-ai2, t, __builtin_fma(-kb, gi2, r2));
           }
           g = gnew;
         }
-        return true;
+        // everything that consumes the hand-over row is computed BEFORE the record's stores are issued
+        asm volatile("" : "+v"(g), "+v"(g1)::"memory");
+        // the step's record: {G_kj, kb_j} per row, then (lane 0) the scalars and the flag
+        s_gk[kk * kRowsWG + lane] = make_double2(gpub, kb);
+        if (lane == 0) {
+          double2* sc = reinterpret_cast<double2*>(s_sc + (size_t)kk * kScStride);
+          sc[0] = make_double2(innov, rden);
+          sc[1] = make_double2(beta, act ? 1.0 : 0.0);
+          sc[2] = make_double2(xmk, __builtin_fma(Gkk, invM, -mu2));   // prior mean (:66), np.var ddof = 0 (:69, :70)
+          g_ctl_set(&ctl[cSReady], kk + 1);
+        }
+        return ok;
       };
       EFA_BLOCKSTAMP(lane == 0, 0);
 #ifdef EFA_PIPE_BLOCKTIME
@@ -480,41 +499,29 @@ __global__ __launch_bounds__(kGT) void k_pipe_gram(const PipeArgs a) {
       {
         int kk = 0;
         bool ok = true;
-        if (nb >= 4) {
-          ok = pivot_step(0, true, true, false, pa, pb);
-          for (kk = 1; ok && kk + 1 < nb - 2; kk += 2) {  // steady state, two steps per trip
-            ok = pivot_step(kk, true, true, true, pb, pa);
-            if (ok) ok = pivot_step(kk + 1, true, true, true, pa, pb);
+        auto run_block = [&](auto gc_tag) {
+          if (nb >= 4) {
+            ok = pivot_step(0, true, true, false, gc_tag);
+            for (kk = 1; ok && kk < nb - 2; ++kk) ok = pivot_step(kk, true, true, true, gc_tag);  // steady state
           }
-        }
-        // the rest one by one (kk odd: the current constants are in pb)
-        for (; ok && kk < nb; ++kk) {
-          if (kk & 1) ok = pivot_step(kk, kk + 1 < nb, kk + 2 < nb, kk >= 1, pb, pa);
-          else ok = pivot_step(kk, kk + 1 < nb, kk + 2 < nb, kk >= 1, pa, pb);
+          for (; ok && kk < nb; ++kk) ok = pivot_step(kk, kk + 1 < nb, kk + 2 < nb, kk >= 1, gc_tag);
+        };
+        if (gc) run_block(std::true_type());
+        else run_block(std::false_type());
+        if (ok && bad != 0ull) {  // the downdate may have cancelled: abandon the launch (the host falls back)
+          if (lane == 0) give_up();
+          ok = false;
         }
         bailed = !ok;
       }
       EFA_BLOCKSTAMP(lane == 0, 1);
 #ifdef EFA_PIPE_BLOCKTIME
       if (a.dbg != nullptr && lane == 0) a.dbg[(size_t)own0 * 8 + 7] = __builtin_amdgcn_s_memrealtime();
+      if (a.dbg != nullptr && lane == 0) a.dbg[(size_t)own0 * 8 + 4] = (u64)slow_rows;
 #endif
       pm[kRowsWG + lane] = xmv;  // obs-space means of all 64 rows after the block, back to the vector waves
+      (void)bailed;
       __syncthreads();  // B3
-      if (!bailed && g_ctl(&ctl[cBail]) == 0 && is_ob) {
-        a.prior_mean[obj] = o_pm;
-        a.prior_var[obj] = o_pv;
-        double* ck = a.coef + (size_t)obj * kCoefStride;
-        ck[0] = my_asm ? o_in : 0.0;
-        ck[1] = my_asm ? o_rd : 0.0;
-        ck[2] = my_asm ? o_be : 0.0;
-        ck[3] = my_asm ? 1.0 : 0.0;
-        a.assimilated[obj] = my_asm ? 1 : 0;  // :74-76, :149
-        if (my_asm) {
-          const double f = 1.0 - o_be * o_km;  // the ob's own row is scaled by (1 - kb)  (:144-149)
-          a.post_mean[obj] = o_pm + o_km * o_in;  // :130
-          a.post_var[obj] = (f * f) * o_pv;
-        }
-      }
       return;
     }
     // ---------------- helper waves: rows that become pivots later ----------------

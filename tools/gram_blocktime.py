@@ -29,6 +29,7 @@ print("bits", bits, "kind", ctx.get_option("phase_a_kind"))
 print("pivot loop (64 steps):               median %7.0f cycles = %5.0f per step" % (np.median(piv), np.median(piv) / 64))
 print("pivot start -> last record forwarded: median %7.0f cycles = %5.0f per step" % (np.median(blk), np.median(blk) / 64))
 print("last foreign record seen -> pivot start (park, Gram, barriers): median %7.0f cycles" % np.median(pre))
+print("steps per block whose hand-over row was late: median %d" % np.median([t[64 * b, 4] for b in range(first, nb)]))
 rt = np.array([t[64 * b, 7] - t[64 * b, 6] for b in range(first, nb)], dtype=float)
 if rt.min() > 0:
     print("s_memtime ticks per s_memrealtime tick over the pivot loop: median %.2f (x 100 MHz = clock of s_memtime)" % np.median(np.array(piv) / rt))
