@@ -26,12 +26,13 @@ def short(name):
 
 def main():
     src, dst, workload, path = sys.argv[1:5]
+    cmd = sys.argv[5] if len(sys.argv) > 5 else "python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline"
     os.makedirs(os.path.dirname(dst) or ".", exist_ok=True)
     lines = []
     stats = max(glob.glob(os.path.join(src, "stats", "*", "*kernel_stats.csv")), key=os.path.getmtime)
     rows = list(csv.DictReader(open(stats)))
-    lines.append("# rocprofv3 --kernel-trace --stats --output-format csv -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline")
-    lines.append("# (1 warm-up + 3 timed cycles of the headline workload; durations in microseconds)")
+    lines.append("# rocprofv3 --kernel-trace --stats --output-format csv -- " + cmd)
+    lines.append("# (durations in microseconds)")
     lines.append("%-34s %6s %12s %12s %7s" % ("kernel", "calls", "avg_us", "total_us", "pct"))
     avg = {}
     for r in rows:
@@ -56,16 +57,36 @@ def main():
     for k in sorted(set(pmc.get("FETCH_SIZE", {})) | set(pmc.get("WRITE_SIZE", {}))):
         fkb = pmc.get("FETCH_SIZE", {}).get(k, float("nan"))
         wkb = pmc.get("WRITE_SIZE", {}).get(k, float("nan"))
-        stream = k.startswith("k_transform") or k.startswith("k_sweep") or k.startswith("k_form_perts")
+        stream = k.startswith("k_transform") or k.startswith("k_sweep") or k.startswith("k_form_perts") or k.startswith("k_gcm")
         b = (2.0 if stream else 1.0) * fkb * 1024 + wkb * 1024
         traffic[k] = b
         lines.append("%-34s %16.1f %16.1f %18.4g" % (k, fkb, wkb, b))
     lines.append("# * read side doubled (gfx950 FETCH_SIZE correction) for the 16 B/lane streaming kernels")
+    # further counter passes (pmc1, pmc2, ...): per-kernel averages
+    extra = defaultdict(dict)
+    for d in sorted(glob.glob(os.path.join(src, "pmc*"))):
+        if not os.path.isdir(d):
+            continue
+        for f in glob.glob(os.path.join(d, "*", "*counter_collection.csv")):
+            acc = defaultdict(list)
+            for r in csv.DictReader(open(f)):
+                acc[(short(r["Kernel_Name"]), r["Counter_Name"])].append(float(r["Counter_Value"]))
+            for (k, cname), v in acc.items():
+                extra[k][cname] = sum(v) / len(v)
+    if extra:
+        lines.append("")
+        lines.append("# further counter passes (one rocprofv3 --pmc run each, averages per launch)")
+        for k in sorted(extra):
+            if k.startswith("__amd") or k.startswith("k_fill") or k.startswith("k_set"):
+                continue
+            lines.append(k)
+            for cname in sorted(extra[k]):
+                lines.append("    %-28s %18.4g" % (cname, extra[k][cname]))
     open(dst + "_summary.txt", "w").write("\n".join(lines) + "\n")
     print("\n".join(lines))
     tj = os.path.join(os.path.dirname(dst) or ".", "traffic.json")
     t = json.load(open(tj)) if os.path.exists(tj) else {}
-    kname = [k for k in traffic if k.startswith("k_transform" if path == "transform" else "k_sweep")]
+    kname = [k for k in traffic if k.startswith({"transform": "k_transform", "gc": "k_sweep_gc", "gcm": "k_gcm"}.get(path, "k_sweep<"))]
     if kname:
         t["%s:%s" % (workload, path)] = traffic[kname[0]]
         json.dump(t, open(tj, "w"), indent=1, sort_keys=True)
