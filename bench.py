@@ -66,7 +66,6 @@ def parse_args():
     ap.add_argument("--path", default="auto", choices=["auto", "sweep", "transform"])
     ap.add_argument("--obs-batch", type=int, default=None)
     ap.add_argument("--gram", type=int, default=None, help="Phase-A leader in Gram space (library default if omitted)")
-    ap.add_argument("--gc-rows", type=int, default=None, help="one-pass GC sweep: 1 row-per-lane kernel, 0 quad-per-row kernel")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-rows", type=int, default=0, help="rows of the CPU-baseline sample (0: sized to --cpu-seconds)")
     ap.add_argument("--cpu-obs", type=int, default=8, help="timed observations of the CPU baseline (BASELINE.md 3)")
@@ -194,8 +193,6 @@ def main():
         ctx.set_option("obs_batch", args.obs_batch)
     if args.gram is not None:
         ctx.set_option("gram", args.gram)
-    if args.gc_rows is not None:
-        ctx.set_option("gc_rows", args.gc_rows)
     ctx.set_option("timing", 1)
     sh = ShardedEnSRF(eng, n_lead, ncol_g, M, rank=rank, world_size=world)
     rows = sh.rows_local
@@ -274,8 +271,7 @@ def main():
         # physical minimum of ONE state-sweep launch: read + write of the member block (and, in perturbation
         # form, the mean); the fused transform / one-pass GC launches carry means in registers only
         if loc == "GC":
-            kernel = ({1: "k_sweep_gc", 2: "k_gc_rows"}.get(ctx.get_option("gc_kernel"), "k_sweep_gc")
-                      if ctx.get_option("gc_onepass") else "k_sweep")
+            kernel = "k_sweep_gc" if ctx.get_option("gc_onepass") else "k_sweep"
             one_pass = bool(ctx.get_option("gc_onepass"))
             phys_bytes = 16.0 * rows * M if one_pass else 16.0 * rows * (M + 1)
         elif path_name == "transform":

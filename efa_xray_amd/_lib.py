@@ -106,6 +106,15 @@ def load_library(path=None):
     global _lib
     if _lib is not None and path is None:
         return _lib
+    # One HIP runtime per process: the PyTorch wheel bundles its own libamdhip64; if libefa_hip.so pulls in
+    # /opt/rocm's copy first and torch is imported later, torch's copy finds no GPU ("No HIP GPUs are
+    # available").  Where torch is installed (HipEngine / bench.py use it for device memory and RCCL) it is
+    # therefore imported first, so that both resolve to the copy already loaded.
+    if "torch" not in sys.modules:
+        try:
+            import torch  # noqa: F401
+        except ImportError:
+            pass
     # EFA_HIP_LIB: a diagnostic build of the same library (tools/ only; `make -C efa_xray_amd/csrc diag`)
     p = path or os.environ.get("EFA_HIP_LIB") or LIB_PATH
     if not os.path.exists(p):

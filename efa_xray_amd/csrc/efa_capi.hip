@@ -84,8 +84,6 @@ struct efa_ctx {
   long spin_limit = 4000000;
   long pipe_debug = 0;
   long gc_onepass = 1;     // localised state sweep in one pass with per-column-block active lists
-  long gc_rows = 1;        // ... with the row-per-lane kernel (efa_gcrows.hip) when it applies, else the quad kernel
-  long gc_kernel = 0;      // read-only: 1 k_sweep_gc, 2 k_gc_rows (last one-pass sweep)
 
   // --- trajectory recorded by the last obs phase --------------------------
   bool have_traj = false;
@@ -449,13 +447,7 @@ int state_gc_onepass(efa_ctx* c, long rows, const double* xm_in, const double* X
   g.Xout = Xp_out;
   g.xout = xm_out;
   g.fused_members = fused_members;
-  if (c->gc_rows && gc_rows_supported(g)) {
-    EFA_HIP(launch_gc_rows(g, s));
-    c->gc_kernel = 2;
-  } else {
-    EFA_HIP(launch_sweep_gc(g, s));
-    c->gc_kernel = 1;
-  }
+  EFA_HIP(launch_sweep_gc(g, s));
   EFA_HIP(hipStreamSynchronize(s));  // h_off is reused by the next call
   c->state_launches++;
   (void)rows;
@@ -649,8 +641,6 @@ int efa_ctx_set_option(efa_ctx* c, const char* key, long value) {
     c->use_pipeline = value ? 1 : 0;
   } else if (!strcmp(key, "gc_onepass")) {
     c->gc_onepass = value ? 1 : 0;
-  } else if (!strcmp(key, "gc_rows")) {
-    c->gc_rows = value ? 1 : 0;
   } else if (!strcmp(key, "own_stream")) {
     c->stream = c->own_stream;  // back to the context's private non-blocking stream
   } else if (!strcmp(key, "pipe_debug")) {
@@ -675,8 +665,6 @@ int efa_ctx_get_option(efa_ctx* c, const char* key, long* value) {
   else if (!strcmp(key, "pipeline")) *value = c->use_pipeline;
   else if (!strcmp(key, "gc_onepass")) *value = c->gc_onepass;
   else if (!strcmp(key, "gc_active_pairs")) *value = c->gc_active_pairs;
-  else if (!strcmp(key, "gc_rows")) *value = c->gc_rows;
-  else if (!strcmp(key, "gc_kernel")) *value = c->gc_kernel;
   else if (!strcmp(key, "spin_limit")) *value = c->spin_limit;
   else if (!strcmp(key, "phase_a_kind")) *value = c->phase_a_kind;
   else if (!strcmp(key, "pipe_dbg_addr")) *value = (long)reinterpret_cast<uintptr_t>(c->dbg.p);

@@ -139,9 +139,6 @@ hipError_t launch_gc_fill(long ncol, long P, const double* glat, const double* g
                           const double* ob_lon, const double* ob_hw, const double* coef, const long* off, int* idx,
                           double* wts, hipStream_t s);
 hipError_t launch_sweep_gc(const GcSweepArgs& a, hipStream_t s);
-// row-per-lane variant (efa_gcrows.hip): even M <= 128, 16-byte aligned state pointers
-bool gc_rows_supported(const GcSweepArgs& a);
-hipError_t launch_gc_rows(const GcSweepArgs& a, hipStream_t s);
 
 struct TransformArgs {
   const double* Xin;  // [rows][M] perturbations, or full members when fused_members

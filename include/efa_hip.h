@@ -81,11 +81,10 @@ int efa_ctx_set_stream(efa_ctx *ctx, void *hip_stream);
  *          space, falling back to the vector chain if its cancellation guard trips),
  *          "spin_limit" (bound of the pipeline's in-kernel polls),
  *          "gc_onepass" (1: localised state sweep in one pass with per-column-block
- *          active lists, 0: per-batch taper tables), "gc_rows" (1: the one-pass sweep uses the
- *          row-per-lane kernel when M is even and <= 128, 0: always the quad-per-row kernel),
+ *          active lists, 0: per-batch taper tables),
  *          "own_stream" (see above);
  *          read-only: "phase_a_kind" (1 pipeline / 2 per-batch / 3 Gram pipeline, last call),
- *          "gc_kernel" (1 quad-per-row / 2 row-per-lane, last one-pass sweep), "gc_active_pairs"
+ *          "gc_active_pairs"
  *          ((column, ob) pairs with a non-zero taper in the last one-pass sweep) */
 int efa_ctx_set_option(efa_ctx *ctx, const char *key, long value);
 int efa_ctx_get_option(efa_ctx *ctx, const char *key, long *value);

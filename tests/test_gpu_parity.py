@@ -643,39 +643,31 @@ def test_gc_goldens_per_batch_table_path(name):
     assert_parity(orc.format_posterior_state(xbm, Xbp, N), g["post"], name + " post")
 
 
-@pytest.mark.parametrize("rows_kernel", [1, 0])
 @pytest.mark.parametrize("N,M,P,ncol", [(3 * 48 * 64, 40, 300, 48 * 64), (5 * 700, 80, 150, 700), (2 * 1000, 100, 64, 1000),
                                         (7 * 333, 2, 40, 333), (1 * 257, 128, 33, 257), (6 * 64, 6, 20, 64)])
-def test_one_pass_gc_kernels_vs_oracle(rows_kernel, N, M, P, ncol):
-    """The one-pass localised sweep has two kernels -- row per lane (`gc_rows`=1: even M <= 128, ye and the
-    coefficients as scalar loads) and quad per row (`gc_rows`=0) -- both against the oracle, in perturbation form
-    and as prior members -> posterior members, on shapes whose column count is not a multiple of the 16-column
-    block and whose slab count is not a multiple of the 4-slab wave tile."""
+def test_one_pass_gc_sweep_vs_oracle_ragged_shapes(N, M, P, ncol):
+    """The one-pass localised sweep against the oracle, in perturbation form and as prior members -> posterior
+    members, on shapes whose column count is not a multiple of the 16-column block and whose slab count is not a
+    multiple of the 4-slab group; zero-taper rows bit-unchanged."""
     c = _random_case(900 + N + M + P, N, M, P, True, ncol=ncol)
     c["hw"][:] = np.random.default_rng(M).uniform(300, 3000, P)
     xam, Xap, diag = _run_oracle(c)
     ctx = _ctx()
-    ctx.set_option("gc_rows", rows_kernel)
-    try:
-        h_xam, h_Xap, h_diag = _run_hip(c, path="sweep")
-        assert ctx.get_option("gc_kernel") == (2 if rows_kernel else 1)
-        assert_parity(h_xam, xam, "xam")
-        assert_parity(h_Xap, Xap, "Xap")
-        X = ctx.to_device(c["X"])
-        Yp = ctx.to_device(c["HX"])
-        ym = ctx.empty((P,))
-        ctx.form_perts(P, M, Yp, ym, Yp)
-        ctx.obs_phase(M, P, ym, Yp, c["val"], c["err"], c["asm"], 1, c["ob_lat"], c["ob_lon"], c["hw"])
-        post = ctx.empty((N, M))
-        ctx.state_cycle(N, M, X, post, c["lat"].reshape(-1), c["lon"].reshape(-1), c["n_lead"])
-        assert_parity(post.download(), orc.format_posterior_state(xam, Xap, N), "post (state_cycle)")
-        # zero-taper rows come back bit-unchanged in perturbation form (F3)
-        w = np.zeros(ncol, dtype=bool)
-        for k in range(P):
-            if c["asm"][k]:
-                w |= orc.localize_state(c["lat"], c["lon"], c["ob_lat"][k], c["ob_lon"][k], c["hw"][k]).reshape(-1) != 0
-        untouched = np.tile(~w, c["n_lead"])
-        xbm, Xbp = orc.format_prior_state(c["X"], c["HX"])
-        assert np.array_equal(h_Xap[:N][untouched], Xbp[:N][untouched])
-    finally:
-        ctx.set_option("gc_rows", 1)
+    h_xam, h_Xap, h_diag = _run_hip(c, path="sweep")
+    assert_parity(h_xam, xam, "xam")
+    assert_parity(h_Xap, Xap, "Xap")
+    X = ctx.to_device(c["X"])
+    Yp = ctx.to_device(c["HX"])
+    ym = ctx.empty((P,))
+    ctx.form_perts(P, M, Yp, ym, Yp)
+    ctx.obs_phase(M, P, ym, Yp, c["val"], c["err"], c["asm"], 1, c["ob_lat"], c["ob_lon"], c["hw"])
+    post = ctx.empty((N, M))
+    ctx.state_cycle(N, M, X, post, c["lat"].reshape(-1), c["lon"].reshape(-1), c["n_lead"])
+    assert_parity(post.download(), orc.format_posterior_state(xam, Xap, N), "post (state_cycle)")
+    w = np.zeros(ncol, dtype=bool)
+    for k in range(P):
+        if c["asm"][k]:
+            w |= orc.localize_state(c["lat"], c["lon"], c["ob_lat"][k], c["ob_lon"][k], c["hw"][k]).reshape(-1) != 0
+    untouched = np.tile(~w, c["n_lead"])
+    xbm, Xbp = orc.format_prior_state(c["X"], c["HX"])
+    assert np.array_equal(h_Xap[:N][untouched], Xbp[:N][untouched])
