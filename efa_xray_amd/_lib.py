@@ -54,6 +54,12 @@ SIGNATURES = {
     "efa_forward_stencil_dev": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_long, ctypes.c_long, ctypes.c_int,
                                                ctypes.c_void_p, ctypes.c_long, ctypes.c_int, c_int64_p,
                                                c_double_p, ctypes.c_void_p]),
+    "efa_interp_stencils": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int,
+                                           ctypes.c_int, ctypes.c_long, c_double_p, c_double_p, c_double_p, ctypes.c_long,
+                                           ctypes.POINTER(ctypes.c_int32), c_double_p, c_double_p, c_double_p,
+                                           c_int64_p, c_double_p, c_uint8_p]),
+    "efa_forward_interp_dev": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_long, ctypes.c_long, ctypes.c_long, ctypes.c_long,
+                                              ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p]),
     "efa_ensrf_update_dev": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_long, ctypes.c_int, ctypes.c_long,
                                             ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p,
                                             c_double_p, c_double_p, c_uint8_p, ctypes.c_int,
@@ -281,6 +287,33 @@ class Context(object):
         _check(self.lib, self.lib.efa_forward_stencil_dev(
             self.handle, rows, row_offset, M, self._addr(X), P, npt,
             idx.ctypes.data_as(c_int64_p), _dp(wts), self._addr(HX)))
+
+    def interp_stencils(self, nvar, nt, ny, nx, grid_lat, grid_lon, valid_times, ob_var, ob_time, ob_lat, ob_lon,
+                        want_host=True):
+        """f1: build the interpolation stencils of P point obs on the device (they stay in the context for
+        `forward_interp`).  Returns (idx (P,8) int64 global rows, wts (P,8), status (P,) uint8) or None."""
+        glat = np.ascontiguousarray(grid_lat, dtype=np.float64)
+        glon = np.ascontiguousarray(grid_lon, dtype=np.float64)
+        latlon_1d = 1 if glat.ndim == 1 else 0
+        glat, glon = glat.reshape(-1), glon.reshape(-1)
+        vt = np.ascontiguousarray(valid_times, dtype=np.float64).reshape(-1)
+        P = len(ob_var)
+        var = np.ascontiguousarray(ob_var, dtype=np.int32)
+        tim = np.ascontiguousarray(ob_time, dtype=np.float64).reshape(P)
+        lat = np.ascontiguousarray(ob_lat, dtype=np.float64).reshape(P)
+        lon = np.ascontiguousarray(ob_lon, dtype=np.float64).reshape(P)
+        idx = np.full((P, 8), -1, dtype=np.int64)
+        wts = np.zeros((P, 8))
+        st = np.zeros(P, dtype=np.uint8)
+        _check(self.lib, self.lib.efa_interp_stencils(
+            self.handle, int(nvar), int(nt), int(ny), int(nx), latlon_1d, glat.shape[0], _dp(glat), _dp(glon), _dp(vt), P,
+            var.ctypes.data_as(ctypes.POINTER(ctypes.c_int32)), _dp(tim), _dp(lat), _dp(lon),
+            idx.ctypes.data_as(c_int64_p) if want_host else None, _dp(wts) if want_host else None, _u8p(st)))
+        return idx, wts, st
+
+    def forward_interp(self, ncol, col_lo, col_hi, n_lead, M, X, HX):
+        _check(self.lib, self.lib.efa_forward_interp_dev(self.handle, ncol, col_lo, col_hi, n_lead, M, self._addr(X),
+                                                         self._addr(HX)))
 
     @staticmethod
     def _ob_arrays(P, ob_value, ob_error, ob_assim, loc_mode, ob_lat, ob_lon, ob_halfwidth):

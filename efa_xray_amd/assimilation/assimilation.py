@@ -99,10 +99,64 @@ class Assimilation(object):
                     scale_var(k, float(v))
         self.is_inflated = True
 
+    def _default_forward_operator(self):
+        """True when every ob uses `Observation.estimate` as shipped (the reference's point interpolation,
+        observation.py:40-50): then all P estimates are computed on the device.  An ob whose class or
+        instance overrides `estimate` (any other forward operator) is evaluated on the host, one by one."""
+        from efa_xray_amd.observation.observation import Observation
+        return len(self.obs) > 0 and all(
+            type(ob).estimate is Observation.estimate and "estimate" not in vars(ob) for ob in self.obs)
+
+    def _time_axis(self):
+        """The state's valid times and the obs' times on one float axis (seconds for datetime64)."""
+        valids = np.asarray(self.prior.ensemble_times())
+        if valids.dtype.kind == "M":
+            t0 = valids[0]
+            vt = (valids - t0) / np.timedelta64(1, "s")
+            ot = np.array([(np.datetime64(ob.time) - t0) / np.timedelta64(1, "s") for ob in self.obs], dtype=np.float64)
+        else:
+            vt = valids.astype(np.float64)
+            ot = np.array([float(ob.time) for ob in self.obs], dtype=np.float64)
+        return vt, ot
+
+    def device_ob_estimates(self, ctx, X_dev):
+        """(P, M) estimates of the reference's default forward operator as a device array, computed from the
+        state resident at `X_dev` (rows in to_vect() order): the interpolation stencils of all obs are built by
+        `efa_interp_stencils` (nearest-4 search, inverse-distance and time weights: ensemble.py:152-224) and
+        applied by `efa_forward_interp_dev`.  No per-ob Python loop, no host pass over the grid."""
+        prior = self.prior
+        names = prior.vars()
+        try:
+            ob_var = [names.index(ob.obtype) for ob in self.obs]
+        except ValueError as e:
+            raise KeyError("observation type not in the state: %s" % e)
+        vt, ot = self._time_axis()
+        nvar, nt, ny, nx, M = prior.shape()
+        _, _, status = ctx.interp_stencils(nvar, nt, ny, nx, prior.coords["lat"], prior.coords["lon"], vt, ob_var, ot,
+                                           [float(ob.lat) for ob in self.obs], [float(ob.lon) for ob in self.obs],
+                                           want_host=False)
+        if status.any():
+            k = int(np.nonzero(status)[0][0])
+            why = {1: "its time is outside the state's valid times (the reference prints 'Interpolation is outside of "
+                      "time range in state!' and then fails on None.mean(), assimilation.py:46-47)",
+                   2: "a nearest grid index is out of range for 1-D lat/lon (ensemble.py:186-190,227)",
+                   3: "bad variable index"}.get(int(status[k]), "status %d" % status[k])
+            raise ValueError("observation %d cannot be interpolated: %s" % (k, why))
+        P = len(self.obs)
+        HX = ctx.empty((P, M))
+        ncol = ny * nx
+        ctx.forward_interp(ncol, 0, ncol, nvar * nt, M, X_dev, HX)
+        return HX
+
     def compute_ob_estimates(self):
-        """(P, M) ensemble estimates HX[k] = ob_k.estimate(prior): the forward
-        operator loop of assimilation.py:45-46."""
+        """(P, M) ensemble estimates HX[k] = ob_k.estimate(prior): the forward operator loop of
+        assimilation.py:45-46.  With the reference's own point-interpolation operator the whole loop runs on
+        the device (`device_ob_estimates`); user-defined `estimate` methods are called one by one."""
         nobs = len(self.obs)
+        if self._default_forward_operator():
+            ctx = self._context()
+            X = ctx.to_device(np.ascontiguousarray(self.prior.to_vect(), dtype=np.float64))
+            return self.device_ob_estimates(ctx, X).download()
         HX = np.zeros((nobs, self.prior.nmems()))
         for k, ob in enumerate(self.obs):
             HX[k, :] = ob.estimate(self.prior)

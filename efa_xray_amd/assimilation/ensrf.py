@@ -92,19 +92,21 @@ class EnSRF(Assimilation):
         N = prior.nstate()
         M = prior.nmems()
 
-        # forward operator, once per ob from the prior (assimilation.py:45-48)
-        if self.verbose:
-            print("Computing observation priors")
-        HX = self.compute_ob_estimates()
-
         ctx = self._context()
         self._configure(ctx)
         ctx.set_option("timing", 1)
         if self.verbose:
             print("Converting state to vector")
         X = ctx.to_device(np.ascontiguousarray(prior.to_vect(), dtype=np.float64))
+        # forward operator, once per ob from the prior (assimilation.py:45-48): on the device for the
+        # reference's point interpolation, through ob.estimate() for user-defined operators
+        if self.verbose:
+            print("Computing observation priors")
         ym = ctx.empty((max(P, 1),))
-        Yp = ctx.to_device(HX) if P else ctx.empty((1, M))
+        if P and self._default_forward_operator():
+            Yp = self.device_ob_estimates(ctx, X)
+        else:
+            Yp = ctx.to_device(self.compute_ob_estimates()) if P else ctx.empty((1, M))
         if P:
             ctx.form_perts(P, M, Yp, ym, Yp)                   # assimilation.py:46-48
 

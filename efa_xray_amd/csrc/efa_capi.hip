@@ -110,6 +110,9 @@ struct efa_ctx {
   std::vector<long> h_off;
   DevBuf glat, glon;  // grid lat/lon [ncol]
   DevBuf xm_ws;       // means for efa_state_cycle_dev
+  // --- f1: interpolation stencils -------------------------------------------------
+  DevBuf f_glat, f_glon, f_sl, f_cl, f_valids, f_var, f_time, f_lat, f_lon, f_near, f_idx, f_wts, f_status;
+  long f_P = 0;       // observations of the stencil held in f_idx / f_wts (0: none)
   // --- host-memory API buffers ----------------------------------------------
   DevBuf h_xm, h_Xp, h_ym, h_Yp;
   // --- timing -----------------------------------------------------------------
@@ -608,7 +611,7 @@ int efa_ctx_destroy(efa_ctx* c) {
   if (c->stream) (void)hipStreamSynchronize(c->stream);
   DevBuf* bufs[] = {&c->Ye_rec, &c->coef, &c->ob_val, &c->ob_err, &c->ob_asm, &c->ob_lat, &c->ob_lon, &c->ob_hw,
                     &c->d_prior_mean, &c->d_prior_var, &c->d_post_mean, &c->d_post_var, &c->d_assimilated,
-                    &c->Yw, &c->ymw, &c->traj, &c->tw_mat, &c->status, &c->dbg, &c->W, &c->gc_cnt, &c->gc_off, &c->gc_idx, &c->gc_wts, &c->gc_pairs, &c->glat, &c->glon, &c->xm_ws, &c->h_xm, &c->h_Xp, &c->h_ym, &c->h_Yp};
+                    &c->Yw, &c->ymw, &c->traj, &c->tw_mat, &c->status, &c->dbg, &c->W, &c->gc_cnt, &c->gc_off, &c->gc_idx, &c->gc_wts, &c->gc_pairs, &c->glat, &c->glon, &c->xm_ws, &c->f_glat, &c->f_glon, &c->f_sl, &c->f_cl, &c->f_valids, &c->f_var, &c->f_time, &c->f_lat, &c->f_lon, &c->f_near, &c->f_idx, &c->f_wts, &c->f_status, &c->h_xm, &c->h_Xp, &c->h_ym, &c->h_Yp};
   for (DevBuf* b : bufs) b->release();
   for (int i = 0; i < 4; ++i)
     if (c->ev[i]) (void)hipEventDestroy(c->ev[i]);
@@ -756,6 +759,79 @@ int efa_forward_stencil_dev(efa_ctx* c, long rows, long row_offset, int M, const
   di.release();
   dw.release();
   return st;
+}
+
+
+int efa_interp_stencils(efa_ctx* c, int nvar, int nt, int ny, int nx, int latlon_1d, long n_grid, const double* grid_lat,
+                        const double* grid_lon, const double* valid_times, long P, const int32_t* ob_var,
+                        const double* ob_time, const double* ob_lat, const double* ob_lon, int64_t* sten_idx,
+                        double* sten_wts, uint8_t* ob_status) {
+  EFA_TRY(use(c));
+  c->f_P = 0;
+  if (nvar < 1 || nt < 1 || ny < 1 || nx < 1 || n_grid < 1 || P < 0)
+    return fail(EFA_ERR_INVALID, "efa_interp_stencils: bad shape nvar=%d nt=%d ny=%d nx=%d n_grid=%ld P=%ld", nvar, nt, ny, nx, n_grid, P);
+  if (!latlon_1d && n_grid != (long)ny * nx)
+    return fail(EFA_ERR_INVALID, "efa_interp_stencils: 2-D lat/lon need n_grid = ny*nx = %ld, got %ld", (long)ny * nx, n_grid);
+  if (P == 0) return EFA_OK;
+  if (!grid_lat || !grid_lon || !valid_times || !ob_var || !ob_time || !ob_lat || !ob_lon)
+    return fail(EFA_ERR_INVALID, "efa_interp_stencils: null input array");
+  for (int i = 1; i < nt; ++i)
+    if (!(valid_times[i] > valid_times[i - 1])) return fail(EFA_ERR_INVALID, "efa_interp_stencils: valid_times must ascend");
+  const size_t dG = (size_t)n_grid * sizeof(double), dP = (size_t)P * sizeof(double);
+  EFA_TRY(h2d(c, c->f_glat, grid_lat, dG));
+  EFA_TRY(h2d(c, c->f_glon, grid_lon, dG));
+  EFA_TRY(h2d(c, c->f_valids, valid_times, (size_t)nt * sizeof(double)));
+  EFA_TRY(h2d(c, c->f_var, ob_var, (size_t)P * sizeof(int32_t)));
+  EFA_TRY(h2d(c, c->f_time, ob_time, dP));
+  EFA_TRY(h2d(c, c->f_lat, ob_lat, dP));
+  EFA_TRY(h2d(c, c->f_lon, ob_lon, dP));
+  EFA_TRY(c->f_sl.reserve(dG));
+  EFA_TRY(c->f_cl.reserve(dG));
+  EFA_TRY(c->f_near.reserve((size_t)P * 4 * sizeof(long)));
+  EFA_TRY(c->f_idx.reserve((size_t)P * 8 * sizeof(long)));
+  EFA_TRY(c->f_wts.reserve((size_t)P * 8 * sizeof(double)));
+  EFA_TRY(c->f_status.reserve((size_t)P));
+  efa::InterpArgs a{};
+  a.P = P;
+  a.nvar = nvar;
+  a.nt = nt;
+  a.ny = ny;
+  a.nx = nx;
+  a.latlon_1d = latlon_1d ? 1 : 0;
+  a.n_grid = n_grid;
+  a.glat = c->f_glat.as<double>();
+  a.glon = c->f_glon.as<double>();
+  a.sl = c->f_sl.as<double>();
+  a.cl = c->f_cl.as<double>();
+  a.valids = c->f_valids.as<double>();
+  a.ob_var = c->f_var.as<int>();
+  a.ob_time = c->f_time.as<double>();
+  a.ob_lat = c->f_lat.as<double>();
+  a.ob_lon = c->f_lon.as<double>();
+  a.nearest = c->f_near.as<long>();
+  a.sten_idx = c->f_idx.as<long>();
+  a.sten_wts = c->f_wts.as<double>();
+  a.status = c->f_status.as<unsigned char>();
+  hipStream_t s = c->stream;
+  EFA_HIP(efa::launch_interp_stencils(a, s));
+  if (sten_idx) EFA_HIP(hipMemcpyAsync(sten_idx, c->f_idx.p, (size_t)P * 8 * sizeof(int64_t), hipMemcpyDeviceToHost, s));
+  if (sten_wts) EFA_HIP(hipMemcpyAsync(sten_wts, c->f_wts.p, (size_t)P * 8 * sizeof(double), hipMemcpyDeviceToHost, s));
+  if (ob_status) EFA_HIP(hipMemcpyAsync(ob_status, c->f_status.p, (size_t)P, hipMemcpyDeviceToHost, s));
+  EFA_HIP(hipStreamSynchronize(s));  // the caller may reuse its input arrays on return
+  c->f_P = P;
+  return EFA_OK;
+}
+
+int efa_forward_interp_dev(efa_ctx* c, long ncol, long col_lo, long col_hi, long n_lead, int M, const double* X_dev,
+                           double* HX_dev) {
+  EFA_TRY(use(c));
+  if (c->f_P <= 0) return fail(EFA_ERR_INVALID, "efa_forward_interp_dev called before efa_interp_stencils");
+  if (ncol < 1 || col_lo < 0 || col_hi > ncol || col_lo > col_hi || n_lead < 1 || M < 1)
+    return fail(EFA_ERR_INVALID, "efa_forward_interp_dev: bad shard [%ld,%ld) of %ld columns, n_lead=%ld, M=%d", col_lo, col_hi, ncol, n_lead, M);
+  if (!X_dev || !HX_dev) return fail(EFA_ERR_INVALID, "null pointer");
+  EFA_HIP(efa::launch_forward_cols(ncol, col_lo, col_hi, n_lead, M, X_dev, c->f_P, 8, c->f_idx.as<long>(), c->f_wts.as<double>(),
+                                   HX_dev, c->stream));
+  return EFA_OK;
 }
 
 int efa_obs_phase_dev(efa_ctx* c, int M, long P, double* ym_dev, double* Yp_dev, const double* ob_value,

@@ -170,6 +170,24 @@ hipError_t launch_taper_table(long ncol, int nb, const double* grid_lat, const d
 hipError_t launch_forward_stencil(long rows, long row_offset, int M, const double* X, long P,
                                   int npt, const int64_t* idx, const double* wts, double* HX,
                                   hipStream_t s);
+// ---- f1: interpolation stencils on the device (efa_forward.hip) -----------------------------
+struct InterpArgs {
+  long P;
+  int nvar, nt, ny, nx, latlon_1d;
+  long n_grid;
+  const double *glat, *glon;   // device [n_grid]
+  double *sl, *cl;             // device workspace [n_grid]
+  const double* valids;        // device [nt]
+  const int* ob_var;           // device [P]
+  const double *ob_time, *ob_lat, *ob_lon;  // device [P]
+  long* nearest;               // device workspace [P][4]
+  long* sten_idx;              // device out [P][8]
+  double* sten_wts;            // device out [P][8]
+  unsigned char* status;       // device out [P]
+};
+hipError_t launch_interp_stencils(const InterpArgs& a, hipStream_t s);
+hipError_t launch_forward_cols(long ncol, long col_lo, long col_hi, long n_lead, int M, const double* X, long P, int npt,
+                               const long* idx, const double* wts, double* HX, hipStream_t s);
 hipError_t launch_fill_synthetic(long rows, long row_offset, int M, uint64_t seed, double sigma,
                                  double* X, hipStream_t s);
 hipError_t launch_set_identity(int M, double* T, double* w, hipStream_t s);

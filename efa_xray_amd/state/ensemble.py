@@ -203,7 +203,9 @@ class EnsembleState(object):
         glon = np.asarray(self.coords["lon"], dtype=np.float64)
         dist = np.hypot(np.sin(np.radians(glat)) - np.sin(np.radians(lat)),
                         np.cos(np.radians(glon)) - np.cos(np.radians(lon)))
-        nearest_raw = dist.argsort(axis=None)[:npt]
+        # the reference's argsort is NumPy's default (unstable) sort: the order of exact ties is left open;
+        # here, as in the device kernel, ties go to the lower flat index
+        nearest_raw = dist.argsort(axis=None, kind="stable")[:npt]
         return np.unravel_index(nearest_raw, glat.shape)
 
     def haversine(self, loc1, loc2):

@@ -125,6 +125,43 @@ int efa_forward_stencil_dev(efa_ctx *ctx, long rows, long row_offset, int M,
                             const int64_t *idx, const double *wts,
                             double *HX_dev);
 
+/* ---- f1 (search + weights): the reference's default forward operator on the device ------
+ * Observation.estimate -> EnsembleState.interpolate (observation.py:40-50,
+ * ensemble.py:170-239) for P point observations at once, as a linear stencil of up
+ * to 8 (state row, weight) entries per ob:
+ *   space: the 4 grid points nearest in the reference's sin/cos pseudo-distance
+ *          (ensemble.py:152-168; one workgroup scans the grid per ob instead of a
+ *          full argsort; ties go to the lower flat index), weights = inverse
+ *          great-circle distance, normalised; if a point lies within 1 km the
+ *          nearest takes weight 1 (ensemble.py:178-200 -- the reference's own
+ *          exact-match branch raises IndexError as written);
+ *   time:  linear between the two valid times that bracket the ob, with the
+ *          weights AS CODED in ensemble.py:201-224.
+ * Inputs (host arrays): grid_lat/grid_lon [n_grid] degrees, n_grid = ny*nx for
+ *   2-D lat/lon (latlon_1d = 0) or the length of a 1-D coordinate (latlon_1d = 1:
+ *   the reference then uses one index for y and x, ensemble.py:186-190);
+ *   valid_times [nt] ascending on any numeric axis; per ob: ob_var (index of
+ *   Observation.obtype in EnsembleState.vars()), ob_time (same axis), ob_lat, ob_lon.
+ * Outputs: the stencil stays in the context for efa_forward_interp_dev; optional
+ *   host copies sten_idx [P*8] (global state rows in to_vect() order, -1 unused),
+ *   sten_wts [P*8], ob_status [P]: 0 ok, 1 time outside the state's range (the
+ *   reference prints a message and returns None), 2 grid index out of range (1-D
+ *   lat/lon), 3 bad variable index.  Entries 0-3: the earlier valid time, 4-7: the
+ *   later one (or the exact match).  PARITY UNPINNED: interpolate needs a real
+ *   xarray Dataset, so no reference output exists; this follows the source text. */
+int efa_interp_stencils(efa_ctx *ctx, int nvar, int nt, int ny, int nx,
+                        int latlon_1d, long n_grid, const double *grid_lat,
+                        const double *grid_lon, const double *valid_times, long P,
+                        const int32_t *ob_var, const double *ob_time,
+                        const double *ob_lat, const double *ob_lon,
+                        int64_t *sten_idx, double *sten_wts, uint8_t *ob_status);
+/* HX[k,:] = sum of the context's stencil over the entries whose (y,x) column lies in
+ * this shard's [col_lo, col_hi) of the ncol = ny*nx global columns; the shard holds
+ * row lead*(col_hi-col_lo) + (col-col_lo) for lead in [0,n_lead).  A sum all-reduce
+ * over the shards gives the full estimate (compute_ob_priors, assimilation.py:45-46). */
+int efa_forward_interp_dev(efa_ctx *ctx, long ncol, long col_lo, long col_hi,
+                           long n_lead, int M, const double *X_dev, double *HX_dev);
+
 /* ---- a5-a14: the serial EnSRF loop, data resident in HBM -----------------
  * Replaces ensrf.py:50-149 for all P observations.
  *

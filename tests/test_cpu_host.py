@@ -225,13 +225,13 @@ def test_inflation_hook_runs_inside_format_prior_state_and_update():
     for cls, call, kw in ((Assimilation, "format_prior_state", {}), (EnSRF, "update", {}), (EnSRF, "format_prior_state", {})):
         mine = __import__("copy").deepcopy(st)
         a = cls(mine, [], inflation=1.25, verbose=False, **kw)
-        a.compute_ob_estimates = stop.__get__(a)
+        a._context = stop.__get__(a)
         with pytest.raises(Stop):
             getattr(a, call)()
         assert a.is_inflated is True
         assert np.allclose(mine.to_vect(), orc.inflate_constant(st.to_vect(), 1.25), rtol=1e-14, atol=1e-14)
         none = cls(__import__("copy").deepcopy(st), [], inflation=None, verbose=False)
-        none.compute_ob_estimates = stop.__get__(none)
+        none._context = stop.__get__(none)
         with pytest.raises(Stop):
             getattr(none, call)()
         assert none.is_inflated is False and np.array_equal(none.prior.to_vect(), st.to_vect())

@@ -140,3 +140,146 @@ def test_unassimilated_obs_may_lack_a_localize_radius():
     obs[0].assimilate_this, obs[0].localize_radius = True, None
     with pytest.raises(ValueError):
         EnSRF(state, obs, verbose=False, loc="GC").update()
+
+
+# ---------------------------------------------------------------------------
+# f1: the reference's point-interpolation forward operator on the device
+# ---------------------------------------------------------------------------
+def _interp_state(seed, ny=14, nx=18, nt=3, nvar=2, M=12, one_d=False):
+    from efa_xray_amd import EnsembleState
+    rng = np.random.default_rng(seed)
+    if one_d:
+        ny = nx
+        lat, lon = np.linspace(30, 50, nx), np.linspace(230, 262, nx)
+    else:
+        lat, lon = np.meshgrid(np.linspace(30, 50, ny), np.linspace(230, 262, nx), indexing="ij")
+    arr = rng.standard_normal((nvar, nt, ny, nx, 1)) + 2.0 * rng.standard_normal((nvar, nt, ny, nx, M))
+    return EnsembleState.from_array(arr, lat, lon, validtime=np.array([0.0, 3600.0, 7200.0])[:nt]), lat, lon
+
+
+def _point_obs(state, rng, P, lat_rng, lon_rng):
+    from efa_xray_amd import Observation
+    names = state.vars()
+    obs = []
+    for k in range(P):
+        obs.append(Observation(value=float(rng.standard_normal()), obtype=names[k % len(names)],
+                               time=float([0.0, 1800.0, 3600.0, 5000.0, 7200.0][k % 5]), error=1.0,
+                               lat=float(rng.uniform(*lat_rng)), lon=float(rng.uniform(*lon_rng)),
+                               assimilate_this=(k % 6 != 1), localize_radius=1200.0))
+    return obs
+
+
+@pytest.mark.parametrize("one_d", [False, True])
+def test_device_interpolation_stencils_vs_host_and_oracle(one_d):
+    """`efa_interp_stencils` against the host restatement `EnsembleState.interp_stencil` (ensemble.py:152-239) and, for
+    the space weights, against the oracle's `interp_space_weights`.  PARITY UNPINNED on both sides: the reference's
+    interpolate needs a real xarray Dataset, absent from the image; all three follow the source text."""
+    from efa_xray_amd import _lib
+    state, lat, lon = _interp_state(31, one_d=one_d)
+    rng = np.random.default_rng(32)
+    obs = _point_obs(state, rng, 60, (31, 49), (231, 261))
+    # an exact match (within 1 km of a grid point): weight 1 there (the reference raises IndexError, ensemble.py:194-196)
+    if not one_d:
+        obs[7].lat, obs[7].lon = float(lat[5, 6]), float(lon[5, 6])
+    ctx = _lib.get_context(0)
+    nvar, nt, ny, nx, M = state.shape()
+    names = state.vars()
+    idx, wts, st = ctx.interp_stencils(nvar, nt, ny, nx, state.coords["lat"], state.coords["lon"], state.ensemble_times(),
+                                       [names.index(o.obtype) for o in obs], [o.time for o in obs],
+                                       [o.lat for o in obs], [o.lon for o in obs])
+    assert not st.any()
+    X = state.to_vect()
+    for k, o in enumerate(obs):
+        rows, w = o.stencil(state)
+        got = dict((int(r), float(v)) for r, v in zip(idx[k], wts[k]) if r >= 0)
+        assert sorted(got) == sorted(int(r) for r in rows), "ob %d: stencil rows" % k
+        assert_parity(np.array([got[int(r)] for r in rows]), w, "ob %d: stencil weights" % k)
+        if not one_d:
+            iy, ix, sw = orc.interp_space_weights(lat, lon, o.lat, o.lon)
+            tot = {}
+            for r, v in got.items():
+                tot[r % (ny * nx)] = tot.get(r % (ny * nx), 0.0) + v     # summed over the (<= 2) time slots
+            assert_parity(np.array([tot[int(y) * nx + int(x)] for y, x in zip(iy, ix)]), sw, "ob %d: space weights" % k)
+    if not one_d:
+        k7 = dict((int(r), float(v)) for r, v in zip(idx[7], wts[7]) if v != 0.0)
+        assert len(k7) <= 2 and abs(sum(k7.values()) - 1.0) < 1e-15
+    # the estimates: device gather == host gather
+    Xd = ctx.to_device(X)
+    HX = ctx.empty((len(obs), M))
+    ctx.forward_interp(ny * nx, 0, ny * nx, nvar * nt, M, Xd, HX)
+    ref = np.array([o.estimate(state) for o in obs])
+    assert_parity(HX.download(), ref, "HX")
+    # sharded by columns: partial sums add up (the all-reduce payload)
+    acc = np.zeros_like(ref)
+    for lo, hi in ((0, 100), (100, ny * nx)):
+        rows = (np.arange(nvar * nt)[:, None] * (ny * nx) + np.arange(lo, hi)[None, :]).reshape(-1)
+        Xs = ctx.to_device(np.ascontiguousarray(X[rows]))
+        ctx.forward_interp(ny * nx, lo, hi, nvar * nt, M, Xs, HX)
+        acc += HX.download()
+    assert_parity(acc, ref, "sharded HX sum")
+
+
+def test_update_with_the_default_forward_operator_runs_on_device():
+    """`EnSRF.update()` with plain `Observation` objects: no per-ob Python loop -- the stencils are built and applied
+    on the device -- and the result equals the oracle cycle on the host-interpolated estimates."""
+    from efa_xray_amd import EnSRF
+    state, lat, lon = _interp_state(41)
+    rng = np.random.default_rng(42)
+    obs = _point_obs(state, rng, 50, (31, 49), (231, 261))
+    calls = []
+    orig = type(state).interpolate
+    try:
+        type(state).interpolate = lambda self, *a: calls.append(1) or orig(self, *a)
+        flt = EnSRF(state, obs, verbose=False, loc="GC")
+        assert flt._default_forward_operator()
+        post_state, obs_out = flt.update()
+        assert calls == [], "update() went through the per-ob host interpolation"
+    finally:
+        type(state).interpolate = orig
+    X = state.to_vect()
+    HX = np.array([o.estimate(state) for o in obs])
+    nvar, nt, ny, nx, M = state.shape()
+    ref_post, _, _, diag = orc.ensrf_cycle(X, HX, np.array([o.value for o in obs]), np.array([o.error for o in obs]),
+                                           np.array([o.assimilate_this for o in obs]), loc="GC",
+                                           ob_lat=[o.lat for o in obs], ob_lon=[o.lon for o in obs],
+                                           ob_halfwidth=[o.localize_radius for o in obs], grid_lat=lat, grid_lon=lon,
+                                           state_shape=(nvar, nt, ny, nx))
+    assert_parity(post_state.to_vect(), ref_post, "post")
+    assert_parity([o.prior_mean for o in obs_out], diag["prior_mean"], "prior_mean")
+    # compute_ob_priors (assimilation.py:36-49) takes the same route
+    m, p = EnSRF(state, obs, verbose=False).compute_ob_priors()
+    rm, rp = orc.compute_ob_priors(HX)
+    assert_parity(m, rm, "ob prior means")
+    assert_parity(p, rp, "ob prior perturbations")
+    # an ob outside the state's time range: the reference prints a message and then fails on None.mean()
+    obs[3].time = 1e9
+    with pytest.raises(ValueError):
+        EnSRF(state, obs, verbose=False).update()
+
+
+def test_nearest_four_on_a_global_grid_with_mirror_ties():
+    """On a global regular grid the reference's pseudo-distance hypot(sin(lat_g)-sin(lat), cos(lon_g)-cos(lon))
+    (ensemble.py:160-163) cannot tell lon from 360-lon, so its "nearest four" contain mirror points and exact ties;
+    the device kernel must return four points none of which is farther (in that pseudo-distance) than the fourth
+    smallest value, in ascending order, ties towards the lower index."""
+    from efa_xray_amd import _lib
+    ctx = _lib.get_context(0)
+    ny, nx = 91, 180
+    lat2, lon2 = np.meshgrid(np.linspace(-90, 90, ny), np.linspace(0, 358, nx), indexing="ij")
+    rng = np.random.default_rng(5)
+    P = 200
+    olat, olon = rng.uniform(-89, 89, P), rng.uniform(0, 359, P)
+    olat[:20] = lat2[rng.integers(0, ny, 20), 0]          # on grid latitudes: more ties
+    idx, wts, st = ctx.interp_stencils(1, 1, ny, nx, lat2, lon2, [0.0], np.zeros(P, dtype=int), np.zeros(P), olat, olon)
+    assert not st.any()
+    for k in range(P):
+        d = np.hypot(np.sin(np.radians(lat2)) - np.sin(np.radians(olat[k])),
+                     np.cos(np.radians(lon2)) - np.cos(np.radians(olon[k]))).reshape(-1)
+        ref = np.argsort(d, kind="stable")[:4]
+        got = idx[k][idx[k] >= 0]
+        assert len(got) == 4
+        # same pseudo-distances (to the last bit of hypot) in the same order; identical indices where there is no tie
+        assert np.allclose(d[got], d[ref], rtol=4e-16, atol=1e-17)
+        if len(np.unique(d[ref])) == 4 and d[np.argsort(d, kind="stable")[4]] > d[ref[3]] * (1 + 1e-12):
+            assert sorted(got.tolist()) == sorted(ref.tolist())
+        assert abs(wts[k].sum() - 1.0) < 1e-14
