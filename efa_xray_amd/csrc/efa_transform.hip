@@ -51,7 +51,9 @@ struct TShape {
 // HALF: the last chunk holds at most four members (M % 8 in 1..4).  Lane-group g then loads member
 // 8(NU-1)+g alone, so the chunk is ONE K step of the matrix core instead of two half-empty ones
 // (M = 100: 25 steps instead of 26).
-template <int NU, bool HALF>
+// AL: rows are 16-byte aligned (M even and an aligned base): 16-byte loads.  Otherwise (odd M) the two
+// members of a pair are loaded separately -- half the load width, the price of an odd ensemble size only.
+template <int NU, bool HALF, bool AL>
 __device__ __forceinline__ void load_tile(const double* __restrict__ X, long row_clamped, int M, int g,
                                           double (&a)[2 * NU]) {
   const double* p = X + (size_t)row_clamped * M;
@@ -61,17 +63,21 @@ __device__ __forceinline__ void load_tile(const double* __restrict__ X, long row
       const int m = 8 * u + g;
       a[2 * u] = p[(m < M) ? m : M - 1];
       a[2 * u + 1] = 0.0;
-    } else {
+    } else if (AL) {
       int m0 = 8 * u + 2 * g;
       if (u == NU - 1) m0 = (m0 < M) ? m0 : M - 2;  // last chunk may be partial: clamp the address
       const double2 v = *reinterpret_cast<const double2*>(p + m0);
       a[2 * u] = v.x;
       a[2 * u + 1] = v.y;
+    } else {
+      const int m0 = 8 * u + 2 * g;
+      a[2 * u] = p[(m0 < M) ? m0 : M - 1];          // clamped addresses; invalid slots are zeroed at the point of use
+      a[2 * u + 1] = p[(m0 + 1 < M) ? m0 + 1 : M - 1];
     }
   }
 }
 
-template <int NU, bool FUSED, bool HALF>
+template <int NU, bool FUSED, bool HALF, bool AL>
 __global__ __launch_bounds__(kThreadsT) void k_transform(const TransformArgs p) {
   using Sh = TShape<NU>;
   constexpr int NT = Sh::NT;
@@ -108,13 +114,15 @@ __global__ __launch_bounds__(kThreadsT) void k_transform(const TransformArgs p) 
   const long nwaves = (long)gridDim.x * (kThreadsT / 64);
   const int tM = M >> 4, nM = M & 15;  // tile / lane column holding the mean increment
   const long last_row = p.nrows - 1;
-  const bool last_ok = (HALF ? (8 * (NU - 1) + g) : (8 * (NU - 1) + 2 * g)) < M;  // this lane's slots of the last chunk are real members
+  // this lane's two slots of the last chunk are real members?  (the second only matters for an odd M)
+  const bool last_ok = (HALF ? (8 * (NU - 1) + g) : (8 * (NU - 1) + 2 * g)) < M;
+  const bool last_ok1 = !HALF && (8 * (NU - 1) + 2 * g + 1) < M;
 
   double a[2 * NU], an[2 * NU];
   long tile = wave;
   if (tile < ntiles) {
     const long r = tile * 16 + n;
-    load_tile<NU, HALF>(p.Xin, r < last_row ? r : last_row, M, g, a);
+    load_tile<NU, HALF, AL>(p.Xin, r < last_row ? r : last_row, M, g, a);
   }
 
   while (tile < ntiles) {
@@ -130,12 +138,10 @@ __global__ __launch_bounds__(kThreadsT) void k_transform(const TransformArgs p) 
     }
     if (kPrefetchT) {  // prefetch (the last iteration harmlessly re-reads its own tile)
       const long r = (next < ntiles ? next : tile) * 16 + n;
-      load_tile<NU, HALF>(p.Xin, r < last_row ? r : last_row, M, g, an);
+      load_tile<NU, HALF, AL>(p.Xin, r < last_row ? r : last_row, M, g, an);
     }
-    if (!last_ok) {
-      a[2 * NU - 2] = 0.0;
-      a[2 * NU - 1] = 0.0;
-    }
+    if (!last_ok) a[2 * NU - 2] = 0.0;
+    if (!last_ok1) a[2 * NU - 1] = 0.0;
 
     double rmean = 0.0;  // prior mean of row n (FUSED only)
     if (FUSED) {
@@ -149,7 +155,7 @@ __global__ __launch_bounds__(kThreadsT) void k_transform(const TransformArgs p) 
 #pragma unroll
       for (int c = 0; c < 2 * NU - 2; ++c) a[c] -= rmean;
       a[2 * NU - 2] = last_ok ? a[2 * NU - 2] - rmean : 0.0;
-      a[2 * NU - 1] = (last_ok && !HALF) ? a[2 * NU - 1] - rmean : 0.0;
+      a[2 * NU - 1] = last_ok1 ? a[2 * NU - 1] - rmean : 0.0;
     }
 
     v4f64 acc[NT];
@@ -216,7 +222,7 @@ __global__ __launch_bounds__(kThreadsT) void k_transform(const TransformArgs p) 
       for (int c = 0; c < 2 * NU; ++c) a[c] = an[c];
     } else if (next < ntiles) {
       const long r = next * 16 + n;
-      load_tile<NU, HALF>(p.Xin, r < last_row ? r : last_row, M, g, a);
+      load_tile<NU, HALF, AL>(p.Xin, r < last_row ? r : last_row, M, g, a);
     }
     tile = next;
   }
@@ -228,12 +234,12 @@ __global__ __launch_bounds__(kThreadsT) void k_transform(const TransformArgs p) 
 #endif
 }
 
-template <int NU, bool FUSED, bool HALF>
+template <int NU, bool FUSED, bool HALF, bool AL>
 hipError_t transform_launch(const TransformArgs& a, hipStream_t s) {
   using Sh = TShape<NU>;
   const size_t lds = Sh::lds_doubles * sizeof(double);
   if (lds > 64 * 1024) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_transform<NU, FUSED, HALF>),
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_transform<NU, FUSED, HALF, AL>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
   }
@@ -242,25 +248,31 @@ hipError_t transform_launch(const TransformArgs& a, hipStream_t s) {
   long grid = (ntiles + EFA_T_WAVES - 1) / EFA_T_WAVES;
   if (grid > 256L * per_cu) grid = 256L * per_cu;
   if (grid < 1) grid = 1;
-  hipLaunchKernelGGL((k_transform<NU, FUSED, HALF>), dim3((unsigned)grid), dim3(kThreadsT), lds, s, a);
+  hipLaunchKernelGGL((k_transform<NU, FUSED, HALF, AL>), dim3((unsigned)grid), dim3(kThreadsT), lds, s, a);
   return hipGetLastError();
 }
 
 template <int NU>
 hipError_t transform_nu(const TransformArgs& a, hipStream_t s) {
   const int rem = a.M % 8;
-  if (rem != 0 && rem <= 4)
-    return a.fused_members ? transform_launch<NU, true, true>(a, s) : transform_launch<NU, false, true>(a, s);
-  return a.fused_members ? transform_launch<NU, true, false>(a, s) : transform_launch<NU, false, false>(a, s);
+  const bool half = rem != 0 && rem <= 4;
+  const bool al = (a.M % 2 == 0) && (reinterpret_cast<uintptr_t>(a.Xin) & 15u) == 0;
+  if (al) {
+    if (half) return a.fused_members ? transform_launch<NU, true, true, true>(a, s) : transform_launch<NU, false, true, true>(a, s);
+    return a.fused_members ? transform_launch<NU, true, false, true>(a, s) : transform_launch<NU, false, false, true>(a, s);
+  }
+  if (half) return a.fused_members ? transform_launch<NU, true, true, false>(a, s) : transform_launch<NU, false, true, false>(a, s);
+  return a.fused_members ? transform_launch<NU, true, false, false>(a, s) : transform_launch<NU, false, false, false>(a, s);
 }
 
 }  // namespace
 
-bool transform_supported(int M) { return M >= 2 && M <= 128 && (M % 2 == 0); }
+// [T | w] must fit one CU's LDS in MFMA-B order: 2 NU (NU/2 + 1) 64 doubles <= 160 KiB  <=>  M <= 136
+bool transform_supported(int M) { return M >= 2 && M <= 136; }
 
 hipError_t launch_transform(const TransformArgs& a, hipStream_t s) {
   if (!transform_supported(a.M)) return hipErrorInvalidValue;
-  if ((reinterpret_cast<uintptr_t>(a.Xin) & 15u) != 0) return hipErrorInvalidValue;
+  if ((reinterpret_cast<uintptr_t>(a.Xin) & 7u) != 0) return hipErrorInvalidValue;
   if (a.nrows <= 0) return hipSuccess;
   const int nu = (a.M + 7) / 8;
   switch (nu) {
@@ -280,6 +292,7 @@ hipError_t launch_transform(const TransformArgs& a, hipStream_t s) {
     case 14: return transform_nu<14>(a, s);
     case 15: return transform_nu<15>(a, s);
     case 16: return transform_nu<16>(a, s);
+    case 17: return transform_nu<17>(a, s);
     default: return hipErrorInvalidValue;
   }
 }

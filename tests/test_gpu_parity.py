@@ -671,3 +671,28 @@ def test_one_pass_gc_sweep_vs_oracle_ragged_shapes(N, M, P, ncol):
     untouched = np.tile(~w, c["n_lead"])
     xbm, Xbp = orc.format_prior_state(c["X"], c["HX"])
     assert np.array_equal(h_Xap[:N][untouched], Xbp[:N][untouched])
+
+
+@pytest.mark.parametrize("M", [3, 5, 7, 21, 99, 101, 127, 129, 130, 135, 136])
+def test_transform_path_for_odd_and_large_ensembles(M):
+    """The one-pass transform serves every M <= 136, odd sizes included (8-byte row alignment: the member pairs are
+    loaded separately), so no ensemble size falls back to one read+write pass per 64 obs; perturbation form through the
+    host ABI and prior members -> posterior members through efa_state_cycle_dev, both against the oracle."""
+    N, P = 1000 + M, 2 * M + 3
+    c = _random_case(4000 + M, N, M, P, False, frac_assim=1.0)
+    xam, Xap, diag = _run_oracle(c)
+    ctx = _ctx()
+    h_xam, h_Xap, h_diag = _run_hip(c, path="transform")
+    assert_parity(h_xam, xam, "xam")
+    assert_parity(h_Xap, Xap, "Xap")
+    for key in ("prior_mean", "prior_var", "post_mean", "post_var"):
+        assert_parity(h_diag[key], diag[key], key)
+    X = ctx.to_device(c["X"])
+    Yp = ctx.to_device(c["HX"])
+    ym = ctx.empty((P,))
+    ctx.form_perts(P, M, Yp, ym, Yp)
+    ctx.obs_phase(M, P, ym, Yp, c["val"], c["err"], c["asm"])
+    post = ctx.empty((N, M))
+    ctx.state_cycle(N, M, X, post)
+    assert ctx.last_timing()["path"] == 2, "auto must choose the transform (more than M/2 obs assimilated)"
+    assert_parity(post.download(), orc.format_posterior_state(xam, Xap, N), "post (state_cycle)")
