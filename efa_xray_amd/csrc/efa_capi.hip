@@ -82,6 +82,10 @@ struct efa_ctx {
   long use_gram = 1;       // Gram-space leader for the persistent kernel (falls back to the vector chain)
   long use_pipeline = 1;   // persistent Phase-A kernel when it applies (else per-batch kernels)
   long spin_limit = 4000000;
+  long spin_ms = -1;       // wall-time bound of the persistent Phase-A launch; -1: 100 ms + P/100 ms
+  int cu_count = 0;
+  hipStream_t dbg_stream = nullptr;  // diagnostic occupier (options debug_occupy_*)
+  long dbg_occupy_blocks = 0;
   long pipe_debug = 0;
   long gc_onepass = 1;     // localised state sweep in one pass with per-column-block active lists
 
@@ -265,6 +269,8 @@ int obs_phase(efa_ctx* c, int M, long P, double* ym_dev, double* Yp_dev, const d
     pa.assimilated = c->d_assimilated.as<uint8_t>();
     pa.status = c->status.as<int>();
     pa.spin_limit = c->spin_limit;
+    pa.spin_ticks = (c->spin_ms >= 0 ? c->spin_ms : 100 + P / 100) * 100000L;  // s_memrealtime runs at 100 MHz
+    pa.cu_count = c->cu_count;
     pa.debug = (int)c->pipe_debug;
     pa.dbg = nullptr;
     if (c->pipe_debug & 4) {
@@ -275,9 +281,17 @@ int obs_phase(efa_ctx* c, int M, long P, double* ym_dev, double* Yp_dev, const d
     // attempt 0: Gram-space leader (option "gram"); attempt 1: vector-chain pipeline.  A failed
     // attempt (bounded spin expired, or the Gram downdate's cancellation guard) may have let
     // finished workgroups write their rows back, so the obs block is restored before the next.
+    // An attempt is skipped when its grid cannot be co-resident (occupancy query in the launcher), and after an
+    // attempt whose bounded spins EXPIRED (status 1: some workgroups never became resident, e.g. another
+    // kernel holds CUs) the other persistent kernel is not tried either: it has the same residency need.
     for (int attempt = (c->use_gram && pipeline_gram_supported(M, R, loc_mode)) ? 0 : 1; attempt < 2 && !done_by_pipeline;
          ++attempt) {
-      EFA_HIP(attempt == 0 ? launch_pipeline_gram(pa, s) : launch_pipeline(pa, s));
+      const hipError_t le = attempt == 0 ? launch_pipeline_gram(pa, s) : launch_pipeline(pa, s);
+      if (le == hipErrorCooperativeLaunchTooLarge) {
+        (void)hipGetLastError();
+        continue;
+      }
+      EFA_HIP(le);
       int st[2] = {0, 0};
       EFA_HIP(hipMemcpyAsync(st, c->status.p, sizeof(st), hipMemcpyDeviceToHost, s));
       EFA_HIP(hipStreamSynchronize(s));
@@ -290,6 +304,7 @@ int obs_phase(efa_ctx* c, int M, long P, double* ym_dev, double* Yp_dev, const d
         EFA_HIP(hipMemcpyAsync(Yw, Yp_dev, (size_t)P * M * sizeof(double), hipMemcpyDeviceToDevice, s));
         EFA_HIP(hipMemcpyAsync(ymw, ym_dev, dP, hipMemcpyDeviceToDevice, s));
         if (carry_T) EFA_HIP(launch_set_identity(M, Yw + (size_t)P * M, ymw + P, s));
+        if (st[1] == 1) break;  // expired: straight to the per-batch kernels
         if (attempt == 0) {
           EFA_HIP(launch_fill_u64(c->traj.as<unsigned long long>(), (size_t)P * TS, kTrajSentinel, s));
           EFA_HIP(hipMemsetAsync(c->status.p, 0, 2 * sizeof(int), s));
@@ -588,6 +603,7 @@ int efa_ctx_create(int device_id, efa_ctx** out) {
   efa_ctx* c = new (std::nothrow) efa_ctx();
   if (!c) return fail(EFA_ERR_INVALID, "out of host memory");
   c->device = device_id;
+  c->cu_count = prop.multiProcessorCount;
   hipError_t es = hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking);
   if (es != hipSuccess) {
     delete c;
@@ -615,6 +631,10 @@ int efa_ctx_destroy(efa_ctx* c) {
   for (DevBuf* b : bufs) b->release();
   for (int i = 0; i < 4; ++i)
     if (c->ev[i]) (void)hipEventDestroy(c->ev[i]);
+  if (c->dbg_stream) {
+    (void)hipStreamSynchronize(c->dbg_stream);
+    (void)hipStreamDestroy(c->dbg_stream);
+  }
   if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
   delete c;
   return EFA_OK;
@@ -651,6 +671,16 @@ int efa_ctx_set_option(efa_ctx* c, const char* key, long value) {
   } else if (!strcmp(key, "spin_limit")) {
     if (value < 1) return fail(EFA_ERR_INVALID, "spin_limit must be positive");
     c->spin_limit = value;
+  } else if (!strcmp(key, "spin_ms")) {
+    c->spin_ms = value;
+  } else if (!strcmp(key, "debug_occupy_blocks")) {
+    c->dbg_occupy_blocks = value;
+  } else if (!strcmp(key, "debug_occupy_ms")) {
+    // diagnostic: on a stream of its own, debug_occupy_blocks workgroups hold 120 KB of LDS each (one per CU, and no
+    // persistent Phase-A workgroup fits beside one) for `value` ms; value 0 waits for them to finish
+    if (!c->dbg_stream) EFA_HIP(hipStreamCreateWithFlags(&c->dbg_stream, hipStreamNonBlocking));
+    if (value > 0) EFA_HIP(efa::launch_occupy((int)c->dbg_occupy_blocks, 120 * 1024, (double)value, c->dbg_stream));
+    else EFA_HIP(hipStreamSynchronize(c->dbg_stream));
   } else if (!strcmp(key, "threads_hint")) {
   } else {
     return fail(EFA_ERR_INVALID, "unknown option '%s'", key);
@@ -669,6 +699,8 @@ int efa_ctx_get_option(efa_ctx* c, const char* key, long* value) {
   else if (!strcmp(key, "gc_onepass")) *value = c->gc_onepass;
   else if (!strcmp(key, "gc_active_pairs")) *value = c->gc_active_pairs;
   else if (!strcmp(key, "spin_limit")) *value = c->spin_limit;
+  else if (!strcmp(key, "spin_ms")) *value = c->spin_ms;
+  else if (!strcmp(key, "cu_count")) *value = c->cu_count;
   else if (!strcmp(key, "phase_a_kind")) *value = c->phase_a_kind;
   else if (!strcmp(key, "pipe_dbg_addr")) *value = (long)reinterpret_cast<uintptr_t>(c->dbg.p);
   else if (!strcmp(key, "device")) *value = c->device;

@@ -80,7 +80,7 @@ constexpr int kPipeLanes = 4;    // lanes per row in the pipeline kernel (== its
 inline int traj_pad(int M) { return 2 * kPipeLanes * ((M + 2 * kPipeLanes - 1) / (2 * kPipeLanes)); }
 inline long traj_stride(int M) { return traj_pad(M) + kTrajScalars; }
 constexpr int kPipeRowsPerWG = 64;
-constexpr int kPipeMaxWGs = 256;  // one 576-thread workgroup per CU: all co-resident
+constexpr int kPipeMaxWGs = 256;  // one workgroup per CU (320 threads k_pipe, 512 threads k_pipe_gram): all co-resident
 
 struct PipeArgs {
   double* Yp;   // [R][M] obs block (+ extra identity rows), in/out
@@ -100,8 +100,10 @@ struct PipeArgs {
   double* post_mean;
   double* post_var;
   uint8_t* assimilated;
-  int* status;          // [2]: [0] abort flag (in-kernel), [1] 0 ok / 1 timeout
-  long spin_limit;
+  int* status;          // [2]: [0] abort flag (in-kernel), [1] 0 ok / 1 a bounded spin expired / 2 Gram cancellation guard
+  long spin_limit;      // bound of the in-kernel polls (count)
+  long spin_ticks;      // ... and in wall time: s_memrealtime ticks (100 MHz) since the kernel started; 0 = none
+  int cu_count;         // compute units of the device: the launch is refused unless the grid is co-resident
   unsigned long long* dbg;  // diagnostic (debug & 4): [P][8] cycle stamps of the leader chain, else null
   int debug;  // diagnostic bits (single-workgroup timing runs only): 1 no global publication, 2 no prefetch
 };
@@ -191,6 +193,8 @@ hipError_t launch_forward_cols(long ncol, long col_lo, long col_hi, long n_lead,
 hipError_t launch_fill_synthetic(long rows, long row_offset, int M, uint64_t seed, double sigma,
                                  double* X, hipStream_t s);
 hipError_t launch_set_identity(int M, double* T, double* w, hipStream_t s);
+// diagnostic: `blocks` workgroups that hold `lds_bytes` of LDS each and spin for `ms` milliseconds
+hipError_t launch_occupy(int blocks, size_t lds_bytes, double ms, hipStream_t s);
 hipError_t launch_contract_f32(long N, int M, long P, const float* X, const float* Ye, float* C, hipStream_t s);
 
 }  // namespace efa

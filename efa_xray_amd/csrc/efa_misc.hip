@@ -116,6 +116,15 @@ __global__ void k_set_identity(int M, double* __restrict__ T, double* __restrict
   for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < M; i += gridDim.x * blockDim.x) w[i] = 0.0;
 }
 
+// Diagnostic occupier (option "debug_occupy_ms"): holds LDS on as many CUs as it has blocks, for a bounded time
+__global__ void k_occupy(long ticks) {
+  extern __shared__ double hold[];
+  if (threadIdx.x == 0) hold[0] = 1.0;
+  const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+  while ((long)(__builtin_amdgcn_s_memrealtime() - t0) < ticks) __builtin_amdgcn_s_sleep(32);
+  if (hold[0] == 12345.0) hold[1] = 0.0;
+}
+
 inline unsigned grid_for(size_t work_items, int per_block) {
   size_t g = (work_items + per_block - 1) / per_block;
   const size_t cap = 256u * 8u;
@@ -165,6 +174,15 @@ hipError_t launch_fill_synthetic(long rows, long row_offset, int M, uint64_t see
   if (rows <= 0) return hipSuccess;
   hipLaunchKernelGGL(k_fill_synthetic, dim3(grid_for((size_t)rows * M, kThreads)), dim3(kThreads), 0, s, rows,
                      row_offset, M, seed, sigma, X);
+  return hipGetLastError();
+}
+
+hipError_t launch_occupy(int blocks, size_t lds_bytes, double ms, hipStream_t s) {
+  if (blocks <= 0 || ms <= 0) return hipSuccess;
+  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_occupy), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                     (int)lds_bytes);
+  if (e != hipSuccess) return e;
+  hipLaunchKernelGGL(k_occupy, dim3((unsigned)blocks), dim3(64), lds_bytes, s, (long)(ms * 1e5));
   return hipGetLastError();
 }
 

@@ -114,6 +114,10 @@ __global__ __launch_bounds__(kPT) void k_pipe(const PipeArgs a) {
 
   if (tid < 16) ctl[tid] = (tid >= kProg) ? -1 : (tid == kFwd ? (int)(own0 - 1) : 0);
   __syncthreads();
+  // spins are bounded by a poll budget AND by wall time (s_memrealtime, 100 MHz), the latter looked at on the slow
+  // side of a poll loop only
+  const unsigned long long t_start = __builtin_amdgcn_s_memrealtime();
+#define EFA_TIMED_OUT() (a.spin_ticks > 0 && (long)(__builtin_amdgcn_s_memrealtime() - t_start) > a.spin_ticks)
 
   // =====================================================================================
   // loader wave
@@ -148,7 +152,8 @@ __global__ __launch_bounds__(kPT) void k_pipe(const PipeArgs a) {
           if (cnt == d && d < nrec && __all(ok)) cnt = d + 1;
         }
         if (cnt == 0) {
-          if (--spins_left <= 0 || __hip_atomic_load(a.status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0)
+          if (--spins_left <= 0 || __hip_atomic_load(a.status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0 ||
+              ((spins_left & 15) == 0 && EFA_TIMED_OUT()))
             failed = true;
           __builtin_amdgcn_s_sleep(2);
           continue;
@@ -159,7 +164,7 @@ __global__ __launch_bounds__(kPT) void k_pipe(const PipeArgs a) {
           for (;;) {
             const int mn = __builtin_amdgcn_readfirstlane(group8_min(ctl_load_lane(&ctl[kProg + (lane & (kCW - 1))])));
             if (mn >= (int)need) break;
-            if (--spins_left <= 0) {
+            if (--spins_left <= 0 || ((spins_left & 15) == 0 && EFA_TIMED_OUT())) {
               failed = true;
               break;
             }
@@ -187,7 +192,7 @@ __global__ __launch_bounds__(kPT) void k_pipe(const PipeArgs a) {
       // finished record to global memory (agent-scope granules) for the other workgroups
       for (long f = own0; f < own1; ++f) {
         while (ctl_load(&ctl[kReadyYe]) <= (int)f) {
-          if (--spins_left <= 0 || ctl_load(&ctl[kBail]) != 0) {
+          if (--spins_left <= 0 || ctl_load(&ctl[kBail]) != 0 || ((spins_left & 15) == 0 && EFA_TIMED_OUT())) {
             failed = true;
             break;
           }
@@ -316,7 +321,7 @@ __global__ __launch_bounds__(kPT) void k_pipe(const PipeArgs a) {
         bailed = true;
         return;
       }
-      if (--spins_left <= 0) {
+      if (--spins_left <= 0 || ((spins_left & 15) == 0 && EFA_TIMED_OUT())) {
         give_up();
         bailed = true;
         return;
@@ -366,7 +371,7 @@ __global__ __launch_bounds__(kPT) void k_pipe(const PipeArgs a) {
             break;
           }
           spins_left -= 16;
-          if (spins_left <= 0) {
+          if (spins_left <= 0 || EFA_TIMED_OUT()) {
             give_up();
             bailed = true;
             break;
@@ -491,6 +496,11 @@ __global__ __launch_bounds__(256) void k_obs_taper_matrix(long P, long R, const 
 template <int NC>
 hipError_t pipe_launch(const PipeArgs& a, hipStream_t s) {
   const long grid = (a.R + kPipeRowsPerWG - 1) / kPipeRowsPerWG;
+  // every workgroup waits for records of every other: the grid must fit the device at once
+  int per_cu = 0;
+  hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reinterpret_cast<const void*>(&k_pipe<NC>), kPT, 0);
+  if (e != hipSuccess) return e;
+  if (grid > (long)per_cu * a.cu_count) return hipErrorCooperativeLaunchTooLarge;
   hipLaunchKernelGGL((k_pipe<NC>), dim3((unsigned)grid), dim3(kPT), 0, s, a);
   return hipGetLastError();
 }

@@ -161,6 +161,10 @@ __global__ __launch_bounds__(kGT) void k_pipe_gram(const PipeArgs a) {
   } while (0)
 #endif
   long budget = a.spin_limit;
+  // every spin is bounded twice: by a poll budget and by wall time (s_memrealtime, 100 MHz), looked at only on the
+  // slow side of a poll loop; the time bound is what limits the price of a launch that cannot become fully resident
+  const unsigned long long t_start = __builtin_amdgcn_s_memrealtime();
+#define EFA_TIMED_OUT() (a.spin_ticks > 0 && (long)(__builtin_amdgcn_s_memrealtime() - t_start) > a.spin_ticks)
   int polls = 0;
   auto give_up = [&]() {
     __hip_atomic_store(a.status, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -173,7 +177,7 @@ __global__ __launch_bounds__(kGT) void k_pipe_gram(const PipeArgs a) {
       if ((++polls & 15) == 0) {
         if (g_ctl(&ctl[cBail]) != 0) return false;
         budget -= 16;
-        if (budget <= 0) {
+        if (budget <= 0 || EFA_TIMED_OUT()) {
           give_up();
           return false;
         }
@@ -191,7 +195,7 @@ __global__ __launch_bounds__(kGT) void k_pipe_gram(const PipeArgs a) {
       if ((++polls & 15) == 0) {
         if (g_ctl(&ctl[cBail]) != 0) return false;
         budget -= 16;
-        if (budget <= 0) {
+        if (budget <= 0 || EFA_TIMED_OUT()) {
           give_up();
           return false;
         }
@@ -257,7 +261,9 @@ __global__ __launch_bounds__(kGT) void k_pipe_gram(const PipeArgs a) {
           if (cnt == d && d < nrec && __all(ok)) cnt = d + 1;
         }
         if (cnt == 0) {
-          if (--budget <= 0 || __hip_atomic_load(a.status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) failed = true;
+          if (--budget <= 0 || __hip_atomic_load(a.status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0 ||
+              ((budget & 15) == 0 && EFA_TIMED_OUT()))
+            failed = true;
           __builtin_amdgcn_s_sleep(2);
           continue;
         }
@@ -268,7 +274,7 @@ __global__ __launch_bounds__(kGT) void k_pipe_gram(const PipeArgs a) {
             mn = min(mn, __builtin_amdgcn_mov_dpp(mn, 0xB1, 0xF, 0xF, true));
             mn = min(mn, __builtin_amdgcn_mov_dpp(mn, 0x4E, 0xF, 0xF, true));
             if (__builtin_amdgcn_readfirstlane(mn) >= (int)need) break;
-            if (--budget <= 0 || g_ctl(&ctl[cBail]) != 0) {
+            if (--budget <= 0 || g_ctl(&ctl[cBail]) != 0 || ((budget & 15) == 0 && EFA_TIMED_OUT())) {
               failed = true;
               break;
             }
@@ -408,7 +414,7 @@ __global__ __launch_bounds__(kGT) void k_pipe_gram(const PipeArgs a) {
           if ((++polls & 15) == 0) {
             budget -= 16;
             if (g_ctl(&ctl[cBail]) != 0) return false;
-            if (budget <= 0) {
+            if (budget <= 0 || EFA_TIMED_OUT()) {
               if (lane == 0) give_up();
               return false;
             }
@@ -508,8 +514,11 @@ __global__ __launch_bounds__(kGT) void k_pipe_gram(const PipeArgs a) {
         };
         if (gc) run_block(std::true_type());
         else run_block(std::false_type());
-        if (ok && bad != 0ull) {  // the downdate may have cancelled: abandon the launch (the host falls back)
-          if (lane == 0) give_up();
+        if (ok && bad != 0ull) {  // the downdate may have cancelled: abandon the launch (status 2: the host
+          if (lane == 0) {        // re-runs Phase A with the vector-chain kernel)
+            give_up();
+            __hip_atomic_store(a.status + 1, 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          }
           ok = false;
         }
         bailed = !ok;
@@ -731,7 +740,7 @@ __global__ __launch_bounds__(kGT) void k_pipe_gram(const PipeArgs a) {
           if (mine) {  // the chain: publish the next ye
             if ((nu & 3) == 0) {  // recycling guard, amortised over four records
               while (min_prog() < (int)(kg + 1 + 3 - kRingG)) {
-                if (g_ctl(&ctl[cBail]) != 0 || --budget <= 0) {
+                if (g_ctl(&ctl[cBail]) != 0 || --budget <= 0 || ((budget & 15) == 0 && EFA_TIMED_OUT())) {
                   bailed = true;
                   break;
                 }
@@ -826,6 +835,11 @@ hipError_t gram_launch(const PipeArgs& a, hipStream_t s) {
   hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_pipe_gram<NC>),
                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   if (e != hipSuccess) return e;
+  // every workgroup waits for records of every other: the grid must fit the device at once
+  int per_cu = 0;
+  e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reinterpret_cast<const void*>(&k_pipe_gram<NC>), kGT, lds);
+  if (e != hipSuccess) return e;
+  if (grid > (long)per_cu * a.cu_count) return hipErrorCooperativeLaunchTooLarge;
   hipLaunchKernelGGL((k_pipe_gram<NC>), dim3((unsigned)grid), dim3(kGT), lds, s, a);
   return hipGetLastError();
 }

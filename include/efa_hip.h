@@ -79,7 +79,10 @@ int efa_ctx_set_stream(efa_ctx *ctx, void *hip_stream);
  *          one persistent launch when it applies, 0: per-batch kernels),
  *          "gram" (default 1: the persistent launch leads each 64-ob block in Gram
  *          space, falling back to the vector chain if its cancellation guard trips),
- *          "spin_limit" (bound of the pipeline's in-kernel polls),
+ *          "spin_limit" (bound of the pipeline's in-kernel polls), "spin_ms" (its wall-time
+ *          bound: the persistent launch gives up, and the per-batch kernels take over, when a
+ *          wave has waited that long -- e.g. because another kernel keeps part of the grid from
+ *          becoming resident; -1 = 100 ms + P/100 ms),
  *          "gc_onepass" (1: localised state sweep in one pass with per-column-block
  *          active lists, 0: per-batch taper tables),
  *          "own_stream" (see above);

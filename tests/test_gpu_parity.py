@@ -696,3 +696,53 @@ def test_transform_path_for_odd_and_large_ensembles(M):
     ctx.state_cycle(N, M, X, post)
     assert ctx.last_timing()["path"] == 2, "auto must choose the transform (more than M/2 obs assimilated)"
     assert_parity(post.download(), orc.format_posterior_state(xam, Xap, N), "post (state_cycle)")
+
+
+def test_persistent_phase_a_falls_back_within_a_bound_when_the_device_is_occupied():
+    """The persistent Phase-A kernels need their whole grid resident at once.  With 200 of the 256 CUs held by another
+    kernel (a diagnostic occupier: 120 KB of LDS per CU, so no Phase-A workgroup fits beside it) only part of the grid
+    starts; its waves must give up after `spin_ms` of wall time -- not after millions of polls -- the host must go
+    straight to the per-batch kernels (not to the other persistent kernel, which has the same need), and the numbers
+    must be the per-batch kernels' numbers.  Bound checked: 2 x spin_ms + 1 s for the whole call."""
+    import time
+    ctx = _ctx()
+    M, P = 100, 10000
+    rng = np.random.default_rng(77)
+    HX = 3.0 * rng.standard_normal((P, M))
+    val = HX.mean(axis=1) + rng.standard_normal(P)
+    err = rng.uniform(0.5, 2.0, P)
+    asm = np.ones(P, dtype=bool)
+
+    def run():
+        Yp = ctx.to_device(HX)
+        ym = ctx.empty((P,))
+        ctx.form_perts(P, M, Yp, ym, Yp)
+        t0 = time.perf_counter()
+        d = ctx.obs_phase(M, P, ym, Yp, val, err, asm)
+        return d, Yp.download(), time.perf_counter() - t0, ctx.get_option("phase_a_kind")
+
+    assert ctx.get_option("cu_count") == 256
+    try:
+        ctx.set_option("path", 1)
+        ctx.set_option("pipeline", 0)
+        ref, ref_Y, _, kind = run()
+        assert kind == 2
+        ctx.set_option("pipeline", 1)
+        free, free_Y, t_free, kind = run()
+        assert kind == 3                                   # free device: the Gram pipeline runs
+        ctx.set_option("spin_ms", 40)
+        ctx.set_option("debug_occupy_blocks", 200)
+        ctx.set_option("debug_occupy_ms", 1500)            # returns at once: the occupier runs on its own stream
+        time.sleep(0.05)
+        busy, busy_Y, t_busy, kind = run()
+        assert kind == 2, "the persistent launch cannot have completed on 56 CUs"
+        assert t_busy < 2 * 0.040 + 1.0, "fallback took %.3f s" % t_busy
+        for key in ("prior_mean", "prior_var", "post_mean", "post_var"):
+            assert np.array_equal(busy[key], ref[key], equal_nan=True), key
+        assert np.array_equal(busy_Y, ref_Y)
+        assert_parity(free_Y, ref_Y, "pipeline vs per-batch obs rows")
+    finally:
+        ctx.set_option("debug_occupy_ms", 0)               # wait for the occupier
+        ctx.set_option("spin_ms", -1)
+        ctx.set_option("pipeline", 1)
+        ctx.set_option("path", 0)
