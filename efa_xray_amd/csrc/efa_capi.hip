@@ -240,9 +240,9 @@ int obs_phase(efa_ctx* c, int M, long P, double* ym_dev, double* Yp_dev, const d
   if (c->use_pipeline && pipeline_supported(M, R) && tw_fits) {
     const long TS = traj_stride(M);
     EFA_TRY(c->traj.reserve((size_t)P * TS * sizeof(unsigned long long)));
-    EFA_TRY(c->status.reserve(2 * sizeof(int)));
+    EFA_TRY(c->status.reserve(3 * sizeof(int)));
     EFA_HIP(launch_fill_u64(c->traj.as<unsigned long long>(), (size_t)P * TS, kTrajSentinel, s));
-    EFA_HIP(hipMemsetAsync(c->status.p, 0, 2 * sizeof(int), s));
+    EFA_HIP(hipMemsetAsync(c->status.p, 0, 3 * sizeof(int), s));
     PipeArgs pa{};
     pa.Yp = Yw;
     pa.ym = ymw;
@@ -292,7 +292,7 @@ int obs_phase(efa_ctx* c, int M, long P, double* ym_dev, double* Yp_dev, const d
         continue;
       }
       EFA_HIP(le);
-      int st[2] = {0, 0};
+      int st[3] = {0, 0, 0};
       EFA_HIP(hipMemcpyAsync(st, c->status.p, sizeof(st), hipMemcpyDeviceToHost, s));
       EFA_HIP(hipStreamSynchronize(s));
       if (st[0] == 0 && st[1] == 0) {
@@ -304,10 +304,10 @@ int obs_phase(efa_ctx* c, int M, long P, double* ym_dev, double* Yp_dev, const d
         EFA_HIP(hipMemcpyAsync(Yw, Yp_dev, (size_t)P * M * sizeof(double), hipMemcpyDeviceToDevice, s));
         EFA_HIP(hipMemcpyAsync(ymw, ym_dev, dP, hipMemcpyDeviceToDevice, s));
         if (carry_T) EFA_HIP(launch_set_identity(M, Yw + (size_t)P * M, ymw + P, s));
-        if (st[1] == 1) break;  // expired: straight to the per-batch kernels
+        if (st[2] == 0) break;  // not the Gram guard, so a spin expired: straight to the per-batch kernels
         if (attempt == 0) {
           EFA_HIP(launch_fill_u64(c->traj.as<unsigned long long>(), (size_t)P * TS, kTrajSentinel, s));
-          EFA_HIP(hipMemsetAsync(c->status.p, 0, 2 * sizeof(int), s));
+          EFA_HIP(hipMemsetAsync(c->status.p, 0, 3 * sizeof(int), s));
         }
       }
     }

@@ -100,7 +100,7 @@ struct PipeArgs {
   double* post_mean;
   double* post_var;
   uint8_t* assimilated;
-  int* status;          // [2]: [0] abort flag (in-kernel), [1] 0 ok / 1 a bounded spin expired / 2 Gram cancellation guard
+  int* status;          // [3]: [0] abort flag (in-kernel), [1] 1 = given up, [2] 1 = because of the Gram cancellation guard
   long spin_limit;      // bound of the in-kernel polls (count)
   long spin_ticks;      // ... and in wall time: s_memrealtime ticks (100 MHz) since the kernel started; 0 = none
   int cu_count;         // compute units of the device: the launch is refused unless the grid is co-resident

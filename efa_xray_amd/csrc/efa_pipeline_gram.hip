@@ -514,10 +514,10 @@ __global__ __launch_bounds__(kGT) void k_pipe_gram(const PipeArgs a) {
         };
         if (gc) run_block(std::true_type());
         else run_block(std::false_type());
-        if (ok && bad != 0ull) {  // the downdate may have cancelled: abandon the launch (status 2: the host
+        if (ok && bad != 0ull) {  // the downdate may have cancelled: abandon the launch (status[2]: the host
           if (lane == 0) {        // re-runs Phase A with the vector-chain kernel)
             give_up();
-            __hip_atomic_store(a.status + 1, 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(a.status + 2, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
           }
           ok = false;
         }
