@@ -260,7 +260,7 @@ def main():
         value = n_active * (1 if strong else world) / sec_per_step
         path_name = {1: "sweep", 2: "transform"}.get(path_taken, "sweep")
         kind = ctx.get_option("phase_a_kind")
-        pa_kernel = {1: "k_pipe", 2: "k_diag+k_sweep", 3: "k_pipe_gram"}.get(kind, "?")
+        pa_kernel = {1: "k_pipe", 2: "k_diag+k_sweep", 3: "k_pipe_gram", 4: "k_pipe_band"}.get(kind, "?")
         state_step_ms = state_ms / args.steps
         obs_step_ms = obs_ms / args.steps
         avg_launch_ms = state_ms / max(launches, 1)
@@ -299,7 +299,7 @@ def main():
             "dtype": "f64", "data": "synthetic",
             "config": {"workload": wl["desc"], "rows_per_gpu": rows, "rows_global": rows_g, "members": M, "obs": P,
                        "loc": loc or "none", "path": path_name, "obs_batch": ctx.get_option("obs_batch"),
-                       "phase_a": {1: "pipeline", 2: "per-batch", 3: "pipeline-gram"}.get(kind, "?"),
+                       "phase_a": {1: "pipeline", 2: "per-batch", 3: "pipeline-gram", 4: "pipeline-band"}.get(kind, "?"),
                        "sharding": "one global grid split by (y,x) column over the ranks (ShardedEnSRF), obs block "
                                    "replicated, one all-reduce of HX per cycle, no per-observation communication"},
             # whole-cycle rates: algorithmic (effective, counts every ob's nominal pass) and physical

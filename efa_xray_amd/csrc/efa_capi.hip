@@ -79,7 +79,7 @@ struct efa_ctx {
   long obs_batch = 64;
   long path = EFA_PATH_AUTO;
   long timing = 0;
-  long use_gram = 1;       // Gram-space leader for the persistent kernel (falls back to the vector chain)
+  long use_gram = 2;       // persistent kernel's leader: 2 band leader (unlocalised) else Gram leader, 1 Gram leader, 0 vector chain
   long use_pipeline = 1;   // persistent Phase-A kernel when it applies (else per-batch kernels)
   long spin_limit = 4000000;
   long spin_ms = -1;       // wall-time bound of the persistent Phase-A launch; -1: 100 ms + P/100 ms
@@ -115,6 +115,7 @@ struct efa_ctx {
   DevBuf glat, glon;  // grid lat/lon [ncol]
   DevBuf xm_ws;       // means for efa_state_cycle_dev
   // --- f1: interpolation stencils -------------------------------------------------
+  DevBuf fs_idx, fs_wts;  // efa_forward_stencil_dev staging
   DevBuf f_glat, f_glon, f_sl, f_cl, f_valids, f_var, f_time, f_lat, f_lon, f_near, f_idx, f_wts, f_status;
   long f_P = 0;       // observations of the stencil held in f_idx / f_wts (0: none)
   // --- host-memory API buffers ----------------------------------------------
@@ -284,9 +285,11 @@ int obs_phase(efa_ctx* c, int M, long P, double* ym_dev, double* Yp_dev, const d
     // An attempt is skipped when its grid cannot be co-resident (occupancy query in the launcher), and after an
     // attempt whose bounded spins EXPIRED (status 1: some workgroups never became resident, e.g. another
     // kernel holds CUs) the other persistent kernel is not tried either: it has the same residency need.
-    for (int attempt = (c->use_gram && pipeline_gram_supported(M, R, loc_mode)) ? 0 : 1; attempt < 2 && !done_by_pipeline;
-         ++attempt) {
-      const hipError_t le = attempt == 0 ? launch_pipeline_gram(pa, s) : launch_pipeline(pa, s);
+    const int first_kind = (c->use_gram >= 2 && pipeline_band_supported(M, R, loc_mode)) ? 4
+                           : (c->use_gram >= 1 && pipeline_gram_supported(M, R, loc_mode)) ? 3 : 1;
+    for (int attempt = (first_kind == 1) ? 1 : 0; attempt < 2 && !done_by_pipeline; ++attempt) {
+      const int kind = (attempt == 0) ? first_kind : 1;
+      const hipError_t le = kind == 4 ? launch_pipeline_band(pa, s) : kind == 3 ? launch_pipeline_gram(pa, s) : launch_pipeline(pa, s);
       if (le == hipErrorCooperativeLaunchTooLarge) {
         (void)hipGetLastError();
         continue;
@@ -299,7 +302,7 @@ int obs_phase(efa_ctx* c, int M, long P, double* ym_dev, double* Yp_dev, const d
         done_by_pipeline = true;
         c->ye_ptr = reinterpret_cast<const double*>(c->traj.p);
         c->ye_stride = TS;
-        c->phase_a_kind = (attempt == 0) ? 3 : 1;
+        c->phase_a_kind = kind;
       } else {
         EFA_HIP(hipMemcpyAsync(Yw, Yp_dev, (size_t)P * M * sizeof(double), hipMemcpyDeviceToDevice, s));
         EFA_HIP(hipMemcpyAsync(ymw, ym_dev, dP, hipMemcpyDeviceToDevice, s));
@@ -627,7 +630,7 @@ int efa_ctx_destroy(efa_ctx* c) {
   if (c->stream) (void)hipStreamSynchronize(c->stream);
   DevBuf* bufs[] = {&c->Ye_rec, &c->coef, &c->ob_val, &c->ob_err, &c->ob_asm, &c->ob_lat, &c->ob_lon, &c->ob_hw,
                     &c->d_prior_mean, &c->d_prior_var, &c->d_post_mean, &c->d_post_var, &c->d_assimilated,
-                    &c->Yw, &c->ymw, &c->traj, &c->tw_mat, &c->status, &c->dbg, &c->W, &c->gc_cnt, &c->gc_off, &c->gc_idx, &c->gc_wts, &c->gc_pairs, &c->glat, &c->glon, &c->xm_ws, &c->f_glat, &c->f_glon, &c->f_sl, &c->f_cl, &c->f_valids, &c->f_var, &c->f_time, &c->f_lat, &c->f_lon, &c->f_near, &c->f_idx, &c->f_wts, &c->f_status, &c->h_xm, &c->h_Xp, &c->h_ym, &c->h_Yp};
+                    &c->Yw, &c->ymw, &c->traj, &c->tw_mat, &c->status, &c->dbg, &c->W, &c->gc_cnt, &c->gc_off, &c->gc_idx, &c->gc_wts, &c->gc_pairs, &c->glat, &c->glon, &c->xm_ws, &c->fs_idx, &c->fs_wts, &c->f_glat, &c->f_glon, &c->f_sl, &c->f_cl, &c->f_valids, &c->f_var, &c->f_time, &c->f_lat, &c->f_lon, &c->f_near, &c->f_idx, &c->f_wts, &c->f_status, &c->h_xm, &c->h_Xp, &c->h_ym, &c->h_Yp};
   for (DevBuf* b : bufs) b->release();
   for (int i = 0; i < 4; ++i)
     if (c->ev[i]) (void)hipEventDestroy(c->ev[i]);
@@ -659,7 +662,8 @@ int efa_ctx_set_option(efa_ctx* c, const char* key, long value) {
   } else if (!strcmp(key, "timing")) {
     c->timing = value ? 1 : 0;
   } else if (!strcmp(key, "gram")) {
-    c->use_gram = value ? 1 : 0;
+    if (value < 0 || value > 2) return fail(EFA_ERR_INVALID, "gram must be 0, 1 or 2");
+    c->use_gram = value;
   } else if (!strcmp(key, "pipeline")) {
     c->use_pipeline = value ? 1 : 0;
   } else if (!strcmp(key, "gc_onepass")) {
@@ -775,24 +779,17 @@ int efa_forward_stencil_dev(efa_ctx* c, long rows, long row_offset, int M, const
   if (rows < 0 || M < 1 || P < 0 || npt < 1) return fail(EFA_ERR_INVALID, "bad shape");
   if (P == 0) return EFA_OK;
   if (!X_dev || !idx || !wts || !HX_dev) return fail(EFA_ERR_INVALID, "null pointer");
-  DevBuf di, dw;  // per-call staging; freed on return
+  // staging of the stencil in grow-only context buffers (a hipMalloc/hipFree pair per call costs more than the kernel)
   const size_t n = (size_t)P * npt;
-  int st = di.reserve(n * sizeof(int64_t));
-  if (st == EFA_OK) st = dw.reserve(n * sizeof(double));
-  if (st == EFA_OK) {
-    hipError_t e = hipMemcpyAsync(di.p, idx, n * sizeof(int64_t), hipMemcpyHostToDevice, c->stream);
-    if (e == hipSuccess) e = hipMemcpyAsync(dw.p, wts, n * sizeof(double), hipMemcpyHostToDevice, c->stream);
-    if (e == hipSuccess)
-      e = efa::launch_forward_stencil(rows, row_offset, M, X_dev, P, npt, di.as<int64_t>(), dw.as<double>(), HX_dev,
-                                      c->stream);
-    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
-    if (e != hipSuccess) st = fail(EFA_ERR_HIP, "forward stencil failed: %s", hipGetErrorString(e));
-  }
-  di.release();
-  dw.release();
-  return st;
+  EFA_TRY(c->fs_idx.reserve(n * sizeof(int64_t)));
+  EFA_TRY(c->fs_wts.reserve(n * sizeof(double)));
+  EFA_HIP(hipMemcpyAsync(c->fs_idx.p, idx, n * sizeof(int64_t), hipMemcpyHostToDevice, c->stream));
+  EFA_HIP(hipMemcpyAsync(c->fs_wts.p, wts, n * sizeof(double), hipMemcpyHostToDevice, c->stream));
+  EFA_HIP(efa::launch_forward_stencil(rows, row_offset, M, X_dev, P, npt, c->fs_idx.as<int64_t>(), c->fs_wts.as<double>(),
+                                      HX_dev, c->stream));
+  EFA_HIP(hipStreamSynchronize(c->stream));  // the caller may reuse idx / wts on return
+  return EFA_OK;
 }
-
 
 int efa_interp_stencils(efa_ctx* c, int nvar, int nt, int ny, int nx, int latlon_1d, long n_grid, const double* grid_lat,
                         const double* grid_lon, const double* valid_times, long P, const int32_t* ob_var,

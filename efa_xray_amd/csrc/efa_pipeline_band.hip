@@ -1,0 +1,741 @@
+// Persistent Phase-A pipeline, BAND leader ("k_pipe_band"), unlocalised cycles only.
+//
+// Same launch structure, follower code and inter-workgroup protocol as efa_pipeline_gram.hip (one
+// workgroup per 64 obs rows, rows resident in registers, sentinel-validated agent-scope trajectory
+// records).  What changes is how a workgroup LEADS its own 64 observations.
+//
+// In efa_pipeline_gram.hip every step hands data between waves through LDS: the pivot wave waits
+// for a row from a helper, two helper waves read 32 per-row operand pairs each, the four vector waves
+// pass ye_k from wave to wave (write, flag, poll, read) before ye_{k+1} can be formed.  Stage
+// timings with the production code (tools/gram_blocktime.py, profiles/r02_phase_a_stages.txt):
+// pivot alone 1 060 cycles per step, pivot waiting for its helper row 1 520 (late in 61 of 64
+// steps), vector chain 1 650, followers 950.  Here the block is cut into BANDS of 8 observations and
+// the waves exchange data once per band:
+//
+//   pivot wave   keeps the band's 8 rows of G (lane = column) in registers and runs the 8 steps of
+//                the Gram-space recurrence alone: chain scalars by v_readlane, the rows of the band
+//                that follow are downdated in registers.  Per step it publishes {G_kj, kb_j} and
+//                the ob's scalars; per band the inverse of the band's unit lower triangular factor
+//                (ye_{r0+s} = y_{r0+s} - sum_{t<s} kb^{(t)}_{r0+s} ye_{r0+t}  <=>  YE = L^-1 Y).
+//   2 G waves    hold G as matrix-core accumulator tiles (two tile columns each) and apply a
+//                band's eight rank-one downdates as ONE rank-8 update per tile
+//                (v_mfma_f64_16x16x4_f64, A = gamma_s g^(s)_i, B = g^(s)_j); the tile row of the next band
+//                goes first and is handed to the pivot wave through LDS.
+//   4 vector waves  park the band's 8 rows, form YE = L^-1 Y on the matrix cores (no ye_k -> ye_{k+1}
+//                chain across waves), and apply the band to all 64 rows as one rank-8 update
+//                (A = -kb, B = YE).
+//   loader wave  forwards the band's records to global memory, as before.
+//
+// LDS instructions per observation step in the leading workgroup drop from ~140 to ~25, and no wave
+// waits for another inside a band.  The Gram-space cancellation guard and the fallbacks are those of
+// efa_pipeline_gram.hip.
+#include <type_traits>
+
+#include "efa_device.h"
+#include "efa_internal.h"
+#include "efa_rows.h"
+
+namespace efa {
+namespace {
+
+typedef unsigned long long u64;
+typedef double v4f64 __attribute__((ext_vector_type(4)));
+
+constexpr int kVW = 4;        // vector waves (quad per row, one per SIMD)
+constexpr int kGT = 512;      // threads: 4 vector + pivot + 2 G waves + loader
+constexpr int PLg = kPipeLanes;  // lanes per row: same record layout as efa_pipeline.hip
+constexpr int kRingG = 16;    // LDS ring slots for ye rows (two bands)
+constexpr int kPollG = 4;
+constexpr int kRowsWG = kPipeRowsPerWG;  // 64
+constexpr int kBand = 8;      // observations per band
+constexpr int kNBands = kRowsWG / kBand;
+static_assert(PLg == 4 && kRowsWG == 64, "layout assumptions of the band kernel");
+
+// control words (ints in LDS)
+enum { cReady = 0, cBail = 1, cSReady = 2, cFwd = 3, cProg = 4 /* ..7 */, cBandH = 8 /* ..9 */, cLinv = 10, cPark = 11, cYe = 12 };
+constexpr int kScStride = 8;  // doubles per step in the pivot's scalar records: innov, rden, beta, active, prior mean, prior var, gamma
+
+__device__ __forceinline__ u64 g_traj_load(const u64* p) {
+  return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ void g_traj_store(u64* p, double v) {
+  __hip_atomic_store(p, (u64)__double_as_longlong(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ int g_ctl_lane(const int* p) {
+  const int v = __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+  asm volatile("" ::: "memory");
+  return v;
+}
+__device__ __forceinline__ int g_ctl(const int* p) { return __builtin_amdgcn_readfirstlane(g_ctl_lane(p)); }
+__device__ __forceinline__ void g_ctl_set(int* p, int v) {
+  asm volatile("" ::: "memory");
+  __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+__device__ __forceinline__ double g_rsq(double a) {  // see efa_pipeline.hip: one Newton step suffices
+  const double q = __builtin_amdgcn_rsq(a);
+  const double e = __builtin_fma(-a * q, q, 1.0);
+  const double p = __builtin_fma(0.375, e, 0.5);
+  return __builtin_fma(q * e, p, q);
+}
+__device__ __forceinline__ double g_rcp(double b) {
+  const double r = __builtin_amdgcn_rcp(b);
+  const double e = __builtin_fma(-b, r, 1.0);
+  return __builtin_fma(r, __builtin_fma(e, e, e), r);
+}
+__device__ __forceinline__ double rl(double v, int lane) {  // value held by `lane` (wave-uniform index)
+  const int lo = __builtin_amdgcn_readlane(__double2loint(v), lane);
+  const int hi = __builtin_amdgcn_readlane(__double2hiint(v), lane);
+  return __hiloint2double(hi, lo);
+}
+
+
+template <int NC>
+struct BandShape {
+  static constexpr int PAD = 2 * PLg * NC;
+  static constexpr int TS = PAD + kTrajScalars;
+  static constexpr int SP = PAD + ((2 - PAD % 32) + 32) % 32;  // park tile row stride == 2 (mod 32): conflict-free operand reads
+  static constexpr int SPB = PAD + ((16 - PAD % 32) + 32) % 32;  // band tile row stride == 16 (mod 32): conflict-free B-operand reads
+  static constexpr int UREG = (kRowsWG * SP > kRowsWG * (2 * kRowsWG + kScStride)) ? kRowsWG * SP : kRowsWG * (2 * kRowsWG + kScStride);
+  static constexpr int kLinv = kNBands * kBand * 16;  // L^-1 of every band, [band][t][16]: A-operand order
+  static constexpr int kYb = 2 * kBand * SPB;         // the band's parked rows, double buffered
+  static size_t lds_doubles() { return (size_t)kRingG * TS + kRowsWG * kRowsWG + UREG + 2 * kRowsWG + kLinv + kYb; }
+  static size_t lds_bytes() { return lds_doubles() * sizeof(double) + 32 * sizeof(int); }
+};
+
+template <int NC>
+__global__ __launch_bounds__(kGT) void k_pipe_band(const PipeArgs a) {
+  using Sh = BandShape<NC>;
+  constexpr int PAD = Sh::PAD, TS = Sh::TS, SP = Sh::SP, SPB = Sh::SPB, UREG = Sh::UREG;
+  constexpr int EPL = (TS + 63) / 64;
+  constexpr int NJ = (PAD + 15) / 16;  // accumulator tiles per vector wave in the block's matrix-core layout
+  extern __shared__ __align__(16) double lds[];
+  double* ring = lds;                          // [kRingG][TS]   ye rows (+ scalars in follower mode)
+  double* G_s = ring + kRingG * TS;            // [64][64]       Gram matrix of the block; later the rows handed to the pivot
+  double* U = G_s + kRowsWG * kRowsWG;         // union: Yt[64][SP]  then  {g, kb}[64][64], sc[64][8]
+  double* pm = U + UREG;                       // [2][64]        parked row means / obs-space means
+  double* LinvA = pm + 2 * kRowsWG;            // [8 bands][8][16]  L^-1 of each band: LinvA[b][t][s] = (L^-1)[s][t]
+  double* Yb = LinvA + Sh::kLinv;              // [2][8][SPB]    the band's rows as parked by the vector waves
+  int* ctl = reinterpret_cast<int*>(Yb + Sh::kYb);  // [32]
+  double* Yt = U;
+  double2* s_gk = reinterpret_cast<double2*>(U);  // [step][row] = {G_kj, kb_j}
+  double* s_sc = U + 2 * kRowsWG * kRowsWG;       // [step][8]
+
+  const int tid = threadIdx.x;
+  // wave roles: 0-3 vector, 4 pivot, 5-6 G waves, 7 loader
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
+  const int M = a.M;
+  const long P = a.P, R = a.R;
+  const long own0 = (long)blockIdx.x * kRowsWG;
+  const long own1 = (own0 + kRowsWG < P) ? own0 + kRowsWG : (own0 < P ? P : own0);
+  const int nb = (int)(own1 - own0);  // obs this workgroup leads (0: it only follows)
+  const bool leads = nb > 0;
+  const int nbands = (nb + kBand - 1) / kBand;
+  const double rM1 = 1.0 / (double)(M - 1);
+  const double invM = 1.0 / (double)M;
+
+  if (tid < 32) ctl[tid] = (tid >= cProg && tid < cProg + 4) ? -1 : (tid == cFwd ? (int)(own0 - 1) : 0);
+  __syncthreads();
+
+#ifdef EFA_PIPE_BLOCKTIME  /* make diag: three stamps per block, none inside a loop */
+#define EFA_BLOCKSTAMP(cond, slot)                                                                  \
+  do {                                                                                              \
+    if (a.dbg != nullptr && (cond)) a.dbg[(size_t)own0 * 8 + (slot)] = __builtin_amdgcn_s_memtime(); \
+  } while (0)
+#else
+#define EFA_BLOCKSTAMP(cond, slot) \
+  do {                              \
+  } while (0)
+#endif
+  long budget = a.spin_limit;
+  // every spin is bounded twice: by a poll budget and by wall time (s_memrealtime, 100 MHz), looked at only on the
+  // slow side of a poll loop
+  const unsigned long long t_start = __builtin_amdgcn_s_memrealtime();
+#define EFA_TIMED_OUT() (a.spin_ticks > 0 && (long)(__builtin_amdgcn_s_memrealtime() - t_start) > a.spin_ticks)
+  int polls = 0;
+  auto give_up = [&]() {
+    __hip_atomic_store(a.status, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(a.status + 1, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    g_ctl_set(&ctl[cBail], 1);
+  };
+  // wait until *word > thr; false if the kernel is being abandoned
+  auto wait_gt = [&](const int* word, int thr, bool doze) {
+    while (g_ctl(word) <= thr) {
+      if ((++polls & 15) == 0) {
+        if (g_ctl(&ctl[cBail]) != 0) return false;
+        budget -= 16;
+        if (budget <= 0 || EFA_TIMED_OUT()) {
+          give_up();
+          return false;
+        }
+      }
+      if (doze) __builtin_amdgcn_s_sleep(1);
+    }
+    return true;
+  };
+  // least-advanced consumer of the ye ring: the 4 vector waves and the forwarder
+  auto min_prog = [&]() {
+    int mn = min(g_ctl_lane(&ctl[cProg + (lane & 3)]), g_ctl_lane(&ctl[cFwd]));
+    mn = min(mn, __builtin_amdgcn_mov_dpp(mn, 0xB1, 0xF, 0xF, true));
+    mn = min(mn, __builtin_amdgcn_mov_dpp(mn, 0x4E, 0xF, 0xF, true));
+    return __builtin_amdgcn_readfirstlane(mn);
+  };
+
+  // G = Y Y^T for the block's rows, every wave takes two 16 x 16 tiles (between the block-start barriers)
+  auto form_gram = [&]() {
+    const int I = wave >> 1, J0 = (wave & 1) * 2;
+    v4f64 acc0 = {0.0, 0.0, 0.0, 0.0}, acc1 = {0.0, 0.0, 0.0, 0.0};
+    const double* pa = Yt + (size_t)(16 * I + (lane & 15)) * SP + (lane >> 4);
+    const double* pb0 = Yt + (size_t)(16 * J0 + (lane & 15)) * SP + (lane >> 4);
+    const double* pb1 = pb0 + 16 * SP;
+    for (int s = 0; s < PAD / 4; ++s) {
+      const double av = pa[4 * s], b0 = pb0[4 * s], b1 = pb1[4 * s];
+      acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(av, b0, acc0, 0, 0, 0);
+      acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(av, b1, acc1, 0, 0, 0);
+    }
+    // D layout (probed, tools/mfma_probe.hip): row = 4 v + lane/16, col = lane%16
+#pragma unroll
+    for (int v = 0; v < 4; ++v) {
+      const int gi = 16 * I + 4 * v + (lane >> 4);
+      G_s[gi * kRowsWG + 16 * J0 + (lane & 15)] = acc0[v];
+      G_s[gi * kRowsWG + 16 * (J0 + 1) + (lane & 15)] = acc1[v];
+    }
+  };
+
+  // ======================================================================================
+  // wave 7: loader (follower mode) / forwarder (leader mode)
+  // ======================================================================================
+  if (wave == 7) {
+    // Three phases, each its own loop: follow the records before the block, forward the block, follow the
+    // rest (as ONE loop the compiler waits vmcnt(0) per forwarded record: see efa_pipeline.hip).
+    bool failed = false;
+    int barriers_left = leads ? 3 : 0;
+    auto follow = [&](long next, const long limit) {
+      while (next < limit && !failed) {
+        const int nrec = (int)((limit - next < kPollG) ? (limit - next) : kPollG);
+        u64 v[kPollG][EPL];
+#pragma unroll
+        for (int d = 0; d < kPollG; ++d) {
+          const long kk = next + ((d < nrec) ? d : nrec - 1);
+          const u64* rec = a.traj + (size_t)kk * TS;
+#pragma unroll
+          for (int e = 0; e < EPL; ++e) {
+            const int idx = lane + 64 * e;
+            v[d][e] = g_traj_load(rec + (idx < TS ? idx : TS - 1));
+          }
+        }
+        int cnt = 0;
+#pragma unroll
+        for (int d = 0; d < kPollG; ++d) {
+          bool ok = true;
+#pragma unroll
+          for (int e = 0; e < EPL; ++e) ok = ok && (v[d][e] != kTrajSentinel);
+          if (cnt == d && d < nrec && __all(ok)) cnt = d + 1;
+        }
+        if (cnt == 0) {
+          if (--budget <= 0 || __hip_atomic_load(a.status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0 ||
+              ((budget & 15) == 0 && EFA_TIMED_OUT()))
+            failed = true;
+          __builtin_amdgcn_s_sleep(2);
+          continue;
+        }
+        const long need = next + cnt - 1 - kRingG;  // slots are recycled only once every vector wave consumed them
+        if (need >= 0) {
+          for (;;) {
+            int mn = g_ctl_lane(&ctl[cProg + (lane & 3)]);
+            mn = min(mn, __builtin_amdgcn_mov_dpp(mn, 0xB1, 0xF, 0xF, true));
+            mn = min(mn, __builtin_amdgcn_mov_dpp(mn, 0x4E, 0xF, 0xF, true));
+            if (__builtin_amdgcn_readfirstlane(mn) >= (int)need) break;
+            if (--budget <= 0 || g_ctl(&ctl[cBail]) != 0 || ((budget & 15) == 0 && EFA_TIMED_OUT())) {
+              failed = true;
+              break;
+            }
+          }
+          if (failed) break;
+        }
+#pragma unroll
+        for (int d = 0; d < kPollG; ++d) {
+          if (d < cnt) {
+            double* slot = ring + (size_t)((next + d) % kRingG) * TS;
+#pragma unroll
+            for (int e = 0; e < EPL; ++e) {
+              const int idx = lane + 64 * e;
+              if (idx < TS) slot[idx] = __longlong_as_double((long long)v[d][e]);
+            }
+          }
+        }
+        next += cnt;
+        if (lane == 0) g_ctl_set(&ctl[cReady], (int)next);
+      }
+    };
+    follow(0, (own0 < P) ? own0 : P);
+    EFA_BLOCKSTAMP(lane == 0 && leads, 3);
+    if (leads && !failed) {
+      __syncthreads();  // B1: the vector waves have parked their rows in the tile
+      form_gram();
+      __syncthreads();  // B2: G is complete
+      barriers_left = 1;
+      for (int b = 0; b < nbands && !failed; ++b) {
+        // the band's ye rows are in the ring once every vector wave has added its tiles (4 per band)
+        if (!wait_gt(&ctl[cYe], 4 * (b + 1) - 1, true)) {
+          failed = true;
+          break;
+        }
+        const int s1 = (nb - kBand * b < kBand) ? nb - kBand * b : kBand;
+        for (int s = 0; s < s1; ++s) {
+          const int st = kBand * b + s;
+          const long f = own0 + st;
+          const double* slot = ring + (size_t)(f % kRingG) * TS;
+          const double* sc = s_sc + (size_t)st * kScStride;
+          u64* rec = a.traj + (size_t)f * TS;
+#pragma unroll
+          for (int e = 0; e < EPL; ++e) {
+            const int idx = lane + 64 * e;  // record = ye, then 8 scalars of which the followers read [2..5]
+            const int si = idx - PAD - 2;
+            if (idx < TS) g_traj_store(rec + idx, idx < PAD ? slot[idx] : ((si >= 0 && si < 4) ? sc[si] : 0.0));
+          }
+          if (lane == 0) g_ctl_set(&ctl[cFwd], (int)f);
+          // the ob's diagnostics and sweep coefficients, derived from the pivot's record: the same operations in
+          // the same order as the pivot's own lane k (km = kc rden, kc = G_kk/(M-1)); the ob's own row is scaled
+          // by (1 - kb_k)  (:144-149)
+          if (lane == 0) {
+            const double2 s01 = *reinterpret_cast<const double2*>(sc);      // innov, rden
+            const double2 s23 = *reinterpret_cast<const double2*>(sc + 2);  // beta, active
+            const double2 s45 = *reinterpret_cast<const double2*>(sc + 4);  // prior mean, prior var
+            const double2 gk = s_gk[st * kRowsWG + st];                     // G_kk, kb_k
+            const bool act = s23.y != 0.0;
+            a.prior_mean[f] = s45.x;                                        // :66
+            a.prior_var[f] = s45.y;                                         // :70
+            double* ck = a.coef + (size_t)f * kCoefStride;
+            ck[0] = act ? s01.x : 0.0;
+            ck[1] = act ? s01.y : 0.0;
+            ck[2] = act ? s23.x : 0.0;
+            ck[3] = act ? 1.0 : 0.0;
+            a.assimilated[f] = act ? 1 : 0;                                 // :74-76, :149
+            if (act) {
+              const double km = (gk.x * rM1) * s01.y;                       // :95, :119
+              const double fsc = 1.0 - gk.y;
+              a.post_mean[f] = s45.x + km * s01.x;                          // :130
+              a.post_var[f] = (fsc * fsc) * s45.y;
+            }
+          }
+        }
+      }
+      EFA_BLOCKSTAMP(lane == 0, 2);
+      __syncthreads();  // B3: done with the pivot's records
+      barriers_left = 0;
+      if (!failed) follow(own1, P);
+    }
+    if (failed && lane == 0) give_up();
+    for (; barriers_left > 0; --barriers_left) __syncthreads();  // never leave the others at a barrier
+    return;
+  }
+
+  // ======================================================================================
+  // wave 4 (pivot) and waves 5, 6 (G waves): the Gram-space recurrence of this workgroup's block
+  // ======================================================================================
+  if (wave >= kVW) {
+    if (!leads) return;
+    // the block's ob constants are fetched now, while the wave waits for its block anyway
+    const bool pre_ob = lane < nb;
+    const double pre_err = (wave == kVW && pre_ob) ? a.ob_error[own0 + lane] : 1.0;
+    const double pre_val = (wave == kVW && pre_ob) ? a.ob_value[own0 + lane] : 0.0;
+    const bool pre_asm = (wave == kVW && pre_ob) ? (a.ob_assim[own0 + lane] != 0) : false;
+    const double pre_sq = sqrt(pre_err);
+    __syncthreads();  // B1
+    form_gram();
+    __syncthreads();  // B2
+    if (wave == kVW) {
+      // ---------------- pivot wave: lane j <-> column j of G ----------------
+      // One wave issues in order, so what a step costs is its instruction count: per-ob constants live in the
+      // ob's lane (v_readlane), the band's later rows are downdated in registers, nothing is read from LDS
+      // inside a band, and the step's record is written at its end.  Gain chain as in efa_pipeline_gram.hip:
+      //   kdenom -> q0 = rsq(kdenom) -> { Newton step of q  ||  beta0 = 1/(1 + sqrt(err) q0) } -> beta
+      double mu = pm[lane], xmv = pm[kRowsWG + lane];
+      const bool my_asm = pre_asm;
+      const double err_l = pre_err, sq_l = pre_sq, val_l = pre_val;
+      const u64 asm_mask = __ballot(my_asm);
+      // cancellation guard: an assimilated pivot whose G_kk fell below 1e-3 of its value at block start; accumulated
+      // in the loop, acted upon after the block (a tripped guard abandons the launch: nothing produced meanwhile is used)
+      const double thr = my_asm ? 1e-3 * G_s[lane * kRowsWG + lane] : -1.0;
+      u64 bad = 0ull;
+      bool ok = true;
+      double band[kBand];
+#pragma unroll
+      for (int s = 0; s < kBand; ++s) band[s] = G_s[s * kRowsWG + lane];
+      EFA_BLOCKSTAMP(lane == 0, 0);
+      for (int b = 0; b < nbands && ok; ++b) {
+        const int r0 = kBand * b;
+        const int s1 = (nb - r0 < kBand) ? nb - r0 : kBand;  // steps of this band
+        if (b > 0) {  // the band's rows, current through the previous band, from the two G waves
+          ok = wait_gt(&ctl[cBandH], b - 1, false) && wait_gt(&ctl[cBandH + 1], b - 1, false);
+          if (!ok) break;
+#pragma unroll
+          for (int s = 0; s < kBand; ++s) band[s] = G_s[(r0 + s) * kRowsWG + lane];
+        }
+        // (L^-1)[s][t] for this band, lane t holds column t (lanes >= 8 carry zeros): right-looking,
+        // linv[s'] -= L[s'][s] linv[s] once row s is final
+        double linv[kBand];
+#pragma unroll
+        for (int s = 0; s < kBand; ++s) linv[s] = (lane == s) ? 1.0 : 0.0;
+#pragma unroll
+        for (int s = 0; s < kBand; ++s) {
+          if (s < s1) {  // wave-uniform
+            const int kk = r0 + s;
+            const double g = band[s];
+            const bool act = ((asm_mask >> kk) & 1) != 0;
+            bad |= __ballot(!(g > thr)) & (1ull << kk);
+            const double Gkk = rl(g, kk), muk = rl(mu, kk), xmk = rl(xmv, kk);
+            const double errk = rl(err_l, kk), sqk = rl(sq_l, kk), valk = rl(val_l, kk);
+            const double mu2 = muk * muk;
+            const double kdenom = __builtin_fma(Gkk, invM, errk - mu2);   // var + err  (:69, :91)
+            const double q0 = __builtin_amdgcn_rsq(kdenom);
+            const double e = __builtin_fma(-kdenom * q0, q0, 1.0);
+            const double d = e * __builtin_fma(0.375, e, 0.5);            // q = q0 (1 + d)
+            const double q = __builtin_fma(q0, d, q0);
+            const double rden = q * q;                                    // 1 / kdenom
+            const double sq0 = sqk * q0;
+            const double b0 = 1.0 + sq0;
+            const double r0c = __builtin_amdgcn_rcp(b0);
+            const double eb = __builtin_fma(-b0, r0c, 1.0);
+            const double beta0 = __builtin_fma(r0c, __builtin_fma(eb, eb, eb), r0c);
+            const double beta = __builtin_fma(-((beta0 * beta0) * sq0), d, beta0);  // 1 / (1 + sqrt(err / kdenom))  (:135)
+            const double kc = g * rM1;                                    // :95
+            const double km = act ? kc * rden : 0.0;                      // :119
+            const double kb = beta * km;                                  // :136
+            const double innov = valk - xmk;                              // :85
+            xmv = xmv + km * innov;                                       // :130
+            mu = __builtin_fma(-kb, muk, mu);
+            const double t = __builtin_fma(-kb, Gkk, g);
+            // the rank-one downdate of G by this step is gamma g g^T with gamma = c (2 - c G_kk), c = kb_j / G_kj:
+            // what the G waves apply to their tiles (the band's own rows use the two-term form below)
+            const double cc = act ? (beta * rden) * rM1 : 0.0;
+            const double gam = cc * __builtin_fma(-cc, Gkk, 2.0);
+#pragma unroll
+            for (int s2 = s + 1; s2 < kBand; ++s2) {
+              const double gi = rl(g, r0 + s2), ai = rl(kb, r0 + s2);     // G_k,i and kb_i of row i = r0 + s2
+              band[s2] = __builtin_fma(-ai, t, __builtin_fma(-kb, gi, band[s2]));
+              linv[s2] = __builtin_fma(-ai, linv[s], linv[s2]);           // L[s2][s] = kb_i
+            }
+            // the step's record: {G_kj, kb_j} per row, then (lane 0) the scalars and the flag
+            s_gk[kk * kRowsWG + lane] = make_double2(g, kb);
+            if (lane == 0) {
+              double2* sc = reinterpret_cast<double2*>(s_sc + (size_t)kk * kScStride);
+              sc[0] = make_double2(innov, rden);
+              sc[1] = make_double2(beta, act ? 1.0 : 0.0);
+              sc[2] = make_double2(xmk, __builtin_fma(Gkk, invM, -mu2));   // prior mean (:66), np.var ddof = 0 (:69, :70)
+              sc[3] = make_double2(gam, 0.0);
+              g_ctl_set(&ctl[cSReady], kk + 1);
+            }
+          }
+        }
+        // L^-1 of the band for the vector waves: LinvA[b][t][s], zero where s < t or s >= 8
+        if (lane < kBand) {
+          double* dst = LinvA + ((size_t)b * kBand + lane) * 16;
+#pragma unroll
+          for (int s = 0; s < kBand; ++s) dst[s] = (s < s1) ? linv[s] : 0.0;
+#pragma unroll
+          for (int s = kBand; s < 16; ++s) dst[s] = 0.0;
+        }
+        if (lane == 0) g_ctl_set(&ctl[cLinv], b + 1);
+      }
+      if (ok && bad != 0ull) {  // the downdate may have cancelled: abandon the launch (status[2]: the host re-runs
+        if (lane == 0) {        // Phase A with the vector-chain kernel)
+          give_up();
+          __hip_atomic_store(a.status + 2, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+      }
+      EFA_BLOCKSTAMP(lane == 0, 1);
+      pm[kRowsWG + lane] = xmv;  // obs-space means of all 64 rows after the block, back to the vector waves
+      __syncthreads();  // B3
+      return;
+    }
+    // ---------------- G waves: G as accumulator tiles, one rank-8 update per band ----------------
+    // G wave h holds tile columns J = 2h, 2h+1 of the 4 x 4 tile grid: acc[I][jj][v] in lane l is
+    // G[16 I + 4 v + l/16][16 (2h + jj) + l%16].  After band b (steps r0 .. r0+s1-1):
+    //   G -= sum_s gamma_s g^(s) g^(s)^T  ==  A B with A[i][s] = gamma_s g^(s)_i, B[s][j] = g^(s)_j
+    // Only tile rows that still contain rows of later bands are kept current, the tile row of the next band
+    // first: its 8 rows go back to G_s for the pivot wave.
+    const int h = wave - kVW - 1;  // 0, 1
+    const int lr = lane >> 4, lc = lane & 15;
+    v4f64 acc[4][2];
+#pragma unroll
+    for (int I = 0; I < 4; ++I)
+#pragma unroll
+      for (int jj = 0; jj < 2; ++jj)
+#pragma unroll
+        for (int v = 0; v < 4; ++v) acc[I][jj][v] = G_s[(16 * I + 4 * v + lr) * kRowsWG + 16 * (2 * h + jj) + lc];
+    for (int b = 0; b + 1 < nbands; ++b) {  // nothing follows the last band
+      const int r0 = kBand * b;
+      if (!wait_gt(&ctl[cSReady], r0 + kBand - 1, false)) break;  // (a band before the last one is always full)
+      // B operands: g^(s)_j of this wave's 32 columns, two K slices of four steps
+      double bop[2][2];
+#pragma unroll
+      for (int q = 0; q < 2; ++q)
+#pragma unroll
+        for (int jj = 0; jj < 2; ++jj) bop[q][jj] = s_gk[(r0 + 4 * q + lr) * kRowsWG + 16 * (2 * h + jj) + lc].x;
+      double gam[2];
+#pragma unroll
+      for (int q = 0; q < 2; ++q) gam[q] = s_sc[(size_t)(r0 + 4 * q + lr) * kScStride + 6];
+      const int Inext = (r0 + kBand) >> 4;  // tile row of the next band
+      auto update_row = [&](auto Itag) {
+        constexpr int I = decltype(Itag)::value;
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+          const double av = -gam[q] * s_gk[(r0 + 4 * q + lr) * kRowsWG + 16 * I + lc].x;  // A[i = lc][s = lr]
+#pragma unroll
+          for (int jj = 0; jj < 2; ++jj) acc[I][jj] = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bop[q][jj], acc[I][jj], 0, 0, 0);
+        }
+      };
+      auto hand_over = [&](auto Itag) {  // rows r0+8 .. r0+15 of tile row I (registers v0, v0+1) back to G_s
+        constexpr int I = decltype(Itag)::value;
+        const int v0 = ((r0 + kBand) & 15) >> 2;  // 0 or 2
+#pragma unroll
+        for (int jj = 0; jj < 2; ++jj) {
+          double* dst = G_s + (size_t)(16 * I + 4 * v0 + lr) * kRowsWG + 16 * (2 * h + jj) + lc;
+          dst[0] = (v0 == 0) ? acc[I][jj][0] : acc[I][jj][2];
+          dst[4 * kRowsWG] = (v0 == 0) ? acc[I][jj][1] : acc[I][jj][3];
+        }
+      };
+      switch (Inext) {  // the next band's tile row first, handed over at once
+        case 0: update_row(std::integral_constant<int, 0>()); hand_over(std::integral_constant<int, 0>()); break;
+        case 1: update_row(std::integral_constant<int, 1>()); hand_over(std::integral_constant<int, 1>()); break;
+        case 2: update_row(std::integral_constant<int, 2>()); hand_over(std::integral_constant<int, 2>()); break;
+        default: update_row(std::integral_constant<int, 3>()); hand_over(std::integral_constant<int, 3>()); break;
+      }
+      if (lane == 0) g_ctl_set(&ctl[cBandH + h], b + 1);
+      // the tile rows below it (rows of later bands only)
+      if (Inext < 1) update_row(std::integral_constant<int, 1>());
+      if (Inext < 2) update_row(std::integral_constant<int, 2>());
+      if (Inext < 3) update_row(std::integral_constant<int, 3>());
+    }
+    __syncthreads();  // B3
+    return;
+  }
+
+  // ======================================================================================
+  // waves 0-3: vector waves, rows in registers for the whole kernel
+  // ======================================================================================
+  const int j = lane & (PLg - 1);
+  const int grp = lane / PLg;
+  const int i_loc = wave + kVW * grp;  // consecutive obs in different waves
+  const long row = own0 + i_loc;
+  const bool live = row < R;
+  const bool vec = (M % 2 == 0);
+  double x[2 * NC];
+  double xm = 0.0;
+  if (live) {
+    if (vec) load_row<PLg, NC, true>(a.Yp + (size_t)row * M, M, j, x);
+    else load_row<PLg, NC, false>(a.Yp + (size_t)row * M, M, j, x);
+    xm = a.ym[row];
+  } else {
+#pragma unroll
+    for (int c = 0; c < 2 * NC; ++c) x[c] = 0.0;
+  }
+  int barriers_left = leads ? 3 : 0;
+  bool bailed = false;
+  long k = 0;
+  while (k < P && !bailed) {
+    if (leads && k == own0) {
+      // ---------------- this workgroup's block ----------------
+#pragma unroll
+      for (int c = 0; c < NC; ++c)
+        *reinterpret_cast<double2*>(Yt + (size_t)i_loc * SP + 2 * PLg * c + 2 * j) = make_double2(x[2 * c], x[2 * c + 1]);
+      const double rmean = group_rowsum<PLg, NC>(x) * invM;
+      if (j == 0) {
+        pm[i_loc] = rmean;
+        pm[kRowsWG + i_loc] = xm;
+      }
+      __syncthreads();  // B1: tile and parked means complete
+      form_gram();
+      // For the block the rows change layout: wave w re-reads the 16 rows it has just parked (rows 4 rho + w,
+      // rho = 0..15) as NJ accumulator tiles of v_mfma_f64_16x16x4_f64: register v of tile J in lane l is member
+      // 16 J + (l & 15) of tile row rho = 4 v + (l >> 4).
+      v4f64 xt[NJ];
+      const int lr = lane >> 4, lc = lane & 15;
+#pragma unroll
+      for (int J = 0; J < NJ; ++J)
+#pragma unroll
+        for (int v = 0; v < 4; ++v) xt[J][v] = Yt[(size_t)(16 * v + 4 * lr + wave) * SP + 16 * J + lc];
+      __syncthreads();  // B2: G complete; the tile region now belongs to the pivot wave's records
+      barriers_left = 1;
+      for (int b = 0; b < nbands; ++b) {
+        const int r0 = kBand * b;
+        const int s1 = (nb - r0 < kBand) ? nb - r0 : kBand;
+        double* yb = Yb + (size_t)(b & 1) * kBand * SPB;
+        // (1) park the band's rows (current through the previous band).  Row r0 + s is block row 4 rho + w with
+        //     rho = 2 b + s/4, w = s%4: this wave holds s = w and s = 4 + w in register v = b/2, lane rows
+        //     lr = 2 (b%2) and 2 (b%2) + 1.
+        if ((lr >> 1) == (b & 1)) {
+          double* dst = yb + (size_t)(4 * (lr & 1) + wave) * SPB + lc;
+          switch (b >> 1) {
+#define EFA_PARK_CASE(V)                                           \
+  case V:                                                          \
+    _Pragma("unroll") for (int J = 0; J < NJ; ++J) dst[16 * J] = xt[J][V]; \
+    break;
+            EFA_PARK_CASE(0)
+            EFA_PARK_CASE(1)
+            EFA_PARK_CASE(2)
+            EFA_PARK_CASE(3)
+#undef EFA_PARK_CASE
+          }
+        }
+        if (lane == 0) __hip_atomic_fetch_add(&ctl[cPark], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        // (2) YE = L^-1 Y once every wave has parked and the pivot wave has finished the band
+        if (!wait_gt(&ctl[cPark], 4 * (b + 1) - 1, false) || !wait_gt(&ctl[cLinv], b, true)) {
+          bailed = true;
+          break;
+        }
+        // ring slots of this band are those of band b-2: every consumer must be through with them
+        if (b >= 2) {
+          const int need = (int)(own0 + kBand * (b - 2) + kBand - 1);
+          while (min_prog() < need) {
+            if (g_ctl(&ctl[cBail]) != 0 || --budget <= 0 || ((budget & 15) == 0 && EFA_TIMED_OUT())) {
+              bailed = true;
+              break;
+            }
+          }
+          if (bailed) break;
+        }
+        {
+          const double* la = LinvA + (size_t)b * kBand * 16;
+          const double a0 = la[(size_t)lr * 16 + lc], a1 = la[(size_t)(4 + lr) * 16 + lc];  // A[s = lc][t = 4 q + lr]
+#pragma unroll
+          for (int jt = 0; jt < 2; ++jt) {
+            const int J = wave + 4 * jt;  // this wave's column tiles
+            if (J < NJ) {
+              v4f64 ye = {0.0, 0.0, 0.0, 0.0};
+              ye = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, yb[(size_t)lr * SPB + 16 * J + lc], ye, 0, 0, 0);
+              ye = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, yb[(size_t)(4 + lr) * SPB + 16 * J + lc], ye, 0, 0, 0);
+              // D[s = 4 v + lr][col = lc]: rows s < 8 are ye_{r0+s}
+#pragma unroll
+              for (int v = 0; v < 2; ++v) {
+                const int s = 4 * v + lr;
+                if (16 * J + lc < PAD) ring[(size_t)((own0 + r0 + s) % kRingG) * TS + 16 * J + lc] = ye[v];
+              }
+            }
+          }
+        }
+        if (lane == 0) __hip_atomic_fetch_add(&ctl[cYe], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        // (3) the band applied to all 16 rows of this wave: X -= KB YE (rank s1 <= 8)
+        if (!wait_gt(&ctl[cYe], 4 * (b + 1) - 1, false)) {
+          bailed = true;
+          break;
+        }
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+          const int st = r0 + 4 * q + lr;        // this lane's K slice: step st
+          const bool valid = (4 * q + lr) < s1;
+          double av = s_gk[(valid ? st : r0) * kRowsWG + 4 * lc + wave].y;  // A[rho = lc][s]: kb of block row 4 rho + w
+          av = valid ? -av : 0.0;
+          const double* bs = ring + (size_t)((own0 + (valid ? st : r0)) % kRingG) * TS;
+#pragma unroll
+          for (int J = 0; J < NJ; ++J) {
+            const double bv = valid ? bs[16 * J + lc] : 0.0;
+            xt[J] = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv, xt[J], 0, 0, 0);
+          }
+        }
+        if (lane == 0) g_ctl_set(&ctl[cProg + wave], (int)(own0 + r0 + s1 - 1));  // ring slots up to here consumed
+      }
+      __syncthreads();  // B3: every wave is done with the pivot's records; the tile region is free again
+      barriers_left = 0;
+      if (bailed) break;
+      // back to the follower layout through the tile (each wave reads only rows it wrote itself)
+#pragma unroll
+      for (int J = 0; J < NJ; ++J)
+#pragma unroll
+        for (int v = 0; v < 4; ++v)
+          if (16 * J + lc < PAD) Yt[(size_t)(16 * v + 4 * lr + wave) * SP + 16 * J + lc] = xt[J][v];
+#pragma unroll
+      for (int c = 0; c < NC; ++c) {
+        const double2 v = *reinterpret_cast<const double2*>(Yt + (size_t)i_loc * SP + 2 * PLg * c + 2 * j);
+        x[2 * c] = v.x;
+        x[2 * c + 1] = v.y;
+      }
+      xm = pm[kRowsWG + i_loc];  // the pivot wave carried the obs-space means through the block (:130)
+      k = own1;
+      continue;
+    }
+    // ---------------- follower step: consume record k from the ring ----------------
+    if (!wait_gt(&ctl[cReady], (int)k, true)) {
+      bailed = true;
+      break;
+    }
+    const double* slot = ring + (size_t)(k % kRingG) * TS;
+    double y[2 * NC];
+    lds_read_row<PLg, NC>(slot, j, y);
+    const double2 s23 = *reinterpret_cast<const double2*>(slot + PAD + 2);  // innov, rden
+    const double2 s45 = *reinterpret_cast<const double2*>(slot + PAD + 4);  // beta, active
+    if (lane == 0) g_ctl_set(&ctl[cProg + wave], (int)k);
+    if (__builtin_amdgcn_readfirstlane((int)(s45.y != 0.0)) != 0) {
+      const double dot = group_dot<PLg, NC>(x, y);
+      const double kc = dot * rM1;                        // :95
+      const double km = kc * s23.y;                       // :119
+      xm = xm + km * s23.x;                               // :130
+      const double kb = s45.x * km;                       // :136
+#pragma unroll
+      for (int c = 0; c < 2 * NC; ++c) x[c] = __builtin_fma(-kb, y[c], x[c]);  // :141
+    }
+    ++k;
+  }
+  for (; barriers_left > 0; --barriers_left) __syncthreads();
+  if (bailed || g_ctl(&ctl[cBail]) != 0) return;  // nothing written back: the host re-runs Phase A
+  if (live) {
+    if (vec) store_row<PLg, NC, true>(a.Yp + (size_t)row * M, M, j, x);
+    else store_row<PLg, NC, false>(a.Yp + (size_t)row * M, M, j, x);
+    if (j == 0) a.ym[row] = xm;
+  }
+}
+
+template <int NC>
+hipError_t band_launch(const PipeArgs& a, hipStream_t s) {
+  const long grid = (a.R + kRowsWG - 1) / kRowsWG;
+  const size_t lds = BandShape<NC>::lds_bytes();
+  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_pipe_band<NC>),
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  if (e != hipSuccess) return e;
+  // every workgroup waits for records of every other: the grid must fit the device at once
+  int per_cu = 0;
+  e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reinterpret_cast<const void*>(&k_pipe_band<NC>), kGT, lds);
+  if (e != hipSuccess) return e;
+  if (grid > (long)per_cu * a.cu_count) return hipErrorCooperativeLaunchTooLarge;
+  hipLaunchKernelGGL((k_pipe_band<NC>), dim3((unsigned)grid), dim3(kGT), lds, s, a);
+  return hipGetLastError();
+}
+
+}  // namespace
+
+bool pipeline_band_supported(int M, long R, int loc_mode) {
+  if (loc_mode != 0) return false;  // the rank-one form of the downdate needs kb_j = c G_kj (no taper)
+  if (!(M >= 2 && M <= 128 && R > 0 && (R + kRowsWG - 1) / kRowsWG <= kPipeMaxWGs)) return false;
+  const int nc = (M + 2 * PLg - 1) / (2 * PLg);
+  const int pad = 2 * PLg * nc, ts = pad + kTrajScalars;
+  const int sp = pad + ((2 - pad % 32) + 32) % 32, spb = pad + ((16 - pad % 32) + 32) % 32;
+  const size_t ureg = (size_t)kRowsWG * (sp > 2 * kRowsWG + kScStride ? sp : 2 * kRowsWG + kScStride);
+  const size_t dbl = (size_t)kRingG * ts + kRowsWG * kRowsWG + ureg + 2 * kRowsWG + kNBands * kBand * 16 + 2 * kBand * spb;
+  return dbl * 8 + 128 <= 160 * 1024;
+}
+
+hipError_t launch_pipeline_band(const PipeArgs& a, hipStream_t s) {
+  if (!pipeline_band_supported(a.M, a.R, a.loc_mode) || a.P <= 0) return hipErrorInvalidValue;
+  switch ((a.M + 2 * PLg - 1) / (2 * PLg)) {
+    case 1: return band_launch<1>(a, s);
+    case 2: return band_launch<2>(a, s);
+    case 3: return band_launch<3>(a, s);
+    case 4: return band_launch<4>(a, s);
+    case 5: return band_launch<5>(a, s);
+    case 6: return band_launch<6>(a, s);
+    case 7: return band_launch<7>(a, s);
+    case 8: return band_launch<8>(a, s);
+    case 9: return band_launch<9>(a, s);
+    case 10: return band_launch<10>(a, s);
+    case 11: return band_launch<11>(a, s);
+    case 12: return band_launch<12>(a, s);
+    case 13: return band_launch<13>(a, s);
+    case 14: return band_launch<14>(a, s);
+    case 15: return band_launch<15>(a, s);
+    case 16: return band_launch<16>(a, s);
+    default: return hipErrorInvalidValue;
+  }
+}
+
+}  // namespace efa

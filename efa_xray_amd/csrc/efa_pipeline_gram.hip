@@ -434,6 +434,7 @@ __global__ __launch_bounds__(kGT) void k_pipe_gram(const PipeArgs a) {
         // row kk+2 from its helper, read speculatively (flag first, then the row): the helper puts the
         // row a pivot needs next into G_s before anything else, right after the previous record appears,
         // so it is normally there by now and the round trip is hidden behind the whole gain chain
+        EFA_GSTAMP(lane == 0, own0 + kk, 0);
         int f_early = 0;
         double r2 = 0.0;
         if (has2) {
@@ -496,6 +497,7 @@ __global__ __launch_bounds__(kGT) void k_pipe_gram(const PipeArgs a) {
           sc[2] = make_double2(xmk, __builtin_fma(Gkk, invM, -mu2));   // prior mean (:66), np.var ddof = 0 (:69, :70)
           g_ctl_set(&ctl[cSReady], kk + 1);
         }
+        EFA_GSTAMP(lane == 0, own0 + kk, 1);
         return ok;
       };
       EFA_BLOCKSTAMP(lane == 0, 0);

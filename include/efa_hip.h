@@ -77,8 +77,9 @@ int efa_ctx_set_stream(efa_ctx *ctx, void *hip_stream);
 /* options: "obs_batch" (obs fused per sweep launch, 1..64, default 64),
  *          "path" (EFA_PATH_*), "timing" (0/1), "pipeline" (1: run Phase A as
  *          one persistent launch when it applies, 0: per-batch kernels),
- *          "gram" (default 1: the persistent launch leads each 64-ob block in Gram
- *          space, falling back to the vector chain if its cancellation guard trips),
+ *          "gram" (how the persistent launch leads a 64-ob block: 2 (default) in Gram space in
+ *          bands of 8 obs when the cycle is unlocalised, else as 1; 1 in Gram space step by step;
+ *          0 on the vectors; the Gram-space leaders fall back to 0 if their cancellation guard trips),
  *          "spin_limit" (bound of the pipeline's in-kernel polls), "spin_ms" (its wall-time
  *          bound: the persistent launch gives up, and the per-batch kernels take over, when a
  *          wave has waited that long -- e.g. because another kernel keeps part of the grid from
@@ -86,7 +87,7 @@ int efa_ctx_set_stream(efa_ctx *ctx, void *hip_stream);
  *          "gc_onepass" (1: localised state sweep in one pass with per-column-block
  *          active lists, 0: per-batch taper tables),
  *          "own_stream" (see above);
- *          read-only: "phase_a_kind" (1 pipeline / 2 per-batch / 3 Gram pipeline, last call),
+ *          read-only: "phase_a_kind" (1 pipeline / 2 per-batch / 3 Gram pipeline / 4 band pipeline, last call),
  *          "gc_active_pairs"
  *          ((column, ob) pairs with a non-zero taper in the last one-pass sweep) */
 int efa_ctx_set_option(efa_ctx *ctx, const char *key, long value);

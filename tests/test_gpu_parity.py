@@ -16,7 +16,7 @@ pytestmark = pytest.mark.gpu
 RTOL = 1e-10
 
 
-GRAM_DEFAULT = 1  # library default of the "gram" option (Phase-A leader in Gram space)
+GRAM_DEFAULT = 2  # library default of the "gram" option (2: band leader when unlocalised, else the Gram leader)
 
 
 def _ctx():
@@ -99,10 +99,10 @@ def test_phase_a_per_batch_kernels_and_pipeline_fallback(name):
     ctx = _ctx()
     ctx.set_option("path", 1)
     try:
-        for mode in ("pipeline", "gram", "batch", "expired", "gram_expired"):
+        for mode in ("pipeline", "gram", "band", "batch", "expired", "gram_expired", "band_expired"):
             N, xbm, Xbp = prior_arrays(g)
             ctx.set_option("pipeline", 0 if mode == "batch" else 1)
-            ctx.set_option("gram", 1 if mode.startswith("gram") else 0)
+            ctx.set_option("gram", 2 if mode.startswith("band") else 1 if mode.startswith("gram") else 0)
             ctx.set_option("spin_limit", 1 if mode.endswith("expired") else 4000000)
             diag = ctx.ensrf_update_host(xbm, Xbp, N, g["ob_value"], g["ob_error"], g["ob_assim"],
                                          **golden_kwargs(g))
@@ -111,6 +111,8 @@ def test_phase_a_per_batch_kernels_and_pipeline_fallback(name):
                 assert kind == 1
             if mode == "gram":
                 assert kind == 3
+            if mode == "band":
+                assert kind == (3 if g["loc"] == "GC" else 4)
             if mode == "batch":
                 assert kind == 2
             assert_parity(xbm, g["xam"], "%s %s xam" % (name, mode))
@@ -225,12 +227,12 @@ def _run_oracle(c):
 
 def _run_hip(c, path="auto", batch=32, pipeline=None):
     """pipeline: None library default, 0 per-batch kernels, 1 persistent kernel (vector chain),
-    2 persistent kernel (Gram leader)"""
+    2 persistent kernel (Gram leader), 3 persistent kernel (band leader; Gram leader when localised)"""
     ctx = _ctx()
     ctx.set_option("obs_batch", batch)
     if pipeline is not None:
         ctx.set_option("pipeline", 1 if pipeline else 0)
-        ctx.set_option("gram", 1 if pipeline == 2 else 0)
+        ctx.set_option("gram", 2 if pipeline == 3 else 1 if pipeline == 2 else 0)
     ctx.set_option("path", {"auto": 0, "sweep": 1, "transform": 2}[path])
     xbm, Xbp = orc.format_prior_state(c["X"], c["HX"])
     kw = dict(loc_mode=0)
@@ -258,7 +260,7 @@ SHAPES = [
 def test_seeded_shapes_vs_oracle(N, M, P, loc):
     c = _random_case(100 + N + M + P, N, M, P, loc, ncol=(N // 4 if loc and N % 4 == 0 and N >= 1024 else None))
     xam, Xap, diag = _run_oracle(c)
-    for path, pipe in ((("sweep", 1), ("auto", 1), ("sweep", 0), ("sweep", 2), ("auto", 2)) if not loc
+    for path, pipe in ((("sweep", 1), ("auto", 1), ("sweep", 0), ("sweep", 2), ("auto", 2), ("sweep", 3), ("auto", 3)) if not loc
                        else (("sweep", 1), ("sweep", 0), ("sweep", 2))):
         h_xam, h_Xap, h_diag = _run_hip(c, path=path, pipeline=pipe)
         assert_parity(h_xam, xam, "xam %s" % path)
@@ -278,20 +280,21 @@ def test_gram_leader_cancellation_guard_falls_back():
     c["err"][:40] = 1e-8
     xam, Xap, diag = _run_oracle(c)
     ctx = _ctx()
-    h_xam, h_Xap, h_diag = _run_hip(c, path="sweep", pipeline=2)
-    assert_parity(h_xam, xam, "xam")
-    assert_parity(h_Xap, Xap, "Xap")
-    for key in ("prior_mean", "prior_var", "post_mean", "post_var"):
-        assert_parity(h_diag[key], diag[key], key)
-    # and the guard did trip: the last Phase A was done by the vector-chain kernel
-    ctx.set_option("gram", 1)
-    ctx.set_option("path", 1)
-    xbm, Xbp = orc.format_prior_state(c["X"], c["HX"])
-    ctx.ensrf_update_host(xbm, Xbp, c["N"], c["val"], c["err"], c["asm"], loc_mode=0)
-    kind = ctx.get_option("phase_a_kind")
-    ctx.set_option("gram", GRAM_DEFAULT)
-    ctx.set_option("path", 0)
-    assert kind == 1
+    for pipeline, gram in ((2, 1), (3, 2)):
+        h_xam, h_Xap, h_diag = _run_hip(c, path="sweep", pipeline=pipeline)
+        assert_parity(h_xam, xam, "xam")
+        assert_parity(h_Xap, Xap, "Xap")
+        for key in ("prior_mean", "prior_var", "post_mean", "post_var"):
+            assert_parity(h_diag[key], diag[key], key)
+        # and the guard did trip: the last Phase A was done by the vector-chain kernel
+        ctx.set_option("gram", gram)
+        ctx.set_option("path", 1)
+        xbm, Xbp = orc.format_prior_state(c["X"], c["HX"])
+        ctx.ensrf_update_host(xbm, Xbp, c["N"], c["val"], c["err"], c["asm"], loc_mode=0)
+        kind = ctx.get_option("phase_a_kind")
+        ctx.set_option("gram", GRAM_DEFAULT)
+        ctx.set_option("path", 0)
+        assert kind == 1
 
 
 def test_edge_cases_no_obs_and_none_assimilated():
@@ -482,7 +485,7 @@ def test_persistent_phase_a_at_its_residency_limit():
     asm = rng.random(P) < 0.95
     res = {}
     try:
-        for name, pipe, gram in (("batch", 0, 0), ("chain", 1, 0), ("gram", 1, 1)):
+        for name, pipe, gram in (("batch", 0, 0), ("chain", 1, 0), ("gram", 1, 1), ("band", 1, 2)):
             ctx.set_option("pipeline", pipe)
             ctx.set_option("gram", gram)
             ctx.set_option("path", 0)
@@ -490,9 +493,9 @@ def test_persistent_phase_a_at_its_residency_limit():
             ym = ctx.empty((P,))
             ctx.form_perts(P, M, Yp, ym, Yp)
             d = ctx.obs_phase(M, P, ym, Yp, val, err, asm)
-            assert ctx.get_option("phase_a_kind") == {"batch": 2, "chain": 1, "gram": 3}[name]
+            assert ctx.get_option("phase_a_kind") == {"batch": 2, "chain": 1, "gram": 3, "band": 4}[name]
             res[name] = (Yp.download(), ym.download(), d)
-        for name in ("chain", "gram"):
+        for name in ("chain", "gram", "band"):
             assert_parity(res[name][0], res["batch"][0], name + " obs perturbations")
             assert_parity(res[name][1], res["batch"][1], name + " obs means")
             for key in ("prior_mean", "prior_var", "post_mean", "post_var"):
@@ -729,7 +732,7 @@ def test_persistent_phase_a_falls_back_within_a_bound_when_the_device_is_occupie
         assert kind == 2
         ctx.set_option("pipeline", 1)
         free, free_Y, t_free, kind = run()
-        assert kind == 3                                   # free device: the Gram pipeline runs
+        assert kind == 4                                   # free device: the persistent (band) pipeline runs
         ctx.set_option("spin_ms", 40)
         ctx.set_option("debug_occupy_blocks", 200)
         ctx.set_option("debug_occupy_ms", 1500)            # returns at once: the occupier runs on its own stream
