@@ -146,6 +146,11 @@ __global__ __launch_bounds__(kGT) void k_pipe_band(const PipeArgs a) {
   do {                              \
   } while (0)
 #endif
+#if defined(EFA_PIPE_STAMPS) || defined(EFA_PIPE_BLOCKTIME)
+#define EFA_EXP(bit) ((a.debug & (bit)) != 0)  /* timing experiments (diagnostic builds only): results are wrong */
+#else
+#define EFA_EXP(bit) false
+#endif
   long budget = a.spin_limit;
   // every spin is bounded twice: by a poll budget and by wall time (s_memrealtime, 100 MHz), looked at only on the
   // slow side of a poll loop
@@ -356,21 +361,30 @@ __global__ __launch_bounds__(kGT) void k_pipe_band(const PipeArgs a) {
       const u64 asm_mask = __ballot(my_asm);
       // cancellation guard: an assimilated pivot whose G_kk fell below 1e-3 of its value at block start; accumulated
       // in the loop, acted upon after the block (a tripped guard abandons the launch: nothing produced meanwhile is used)
-      const double thr = my_asm ? 1e-3 * G_s[lane * kRowsWG + lane] : -1.0;
+      double thr = my_asm ? 1e-3 * G_s[lane * kRowsWG + lane] : -1.0;
       u64 bad = 0ull;
       bool ok = true;
       double band[kBand];
 #pragma unroll
       for (int s = 0; s < kBand; ++s) band[s] = G_s[s * kRowsWG + lane];
+      // Every value that came from LDS is pinned HERE: the compiler waits for a load where its result is first used,
+      // with an lgkmcnt count that treats the exec-masked record stores of a step as absent -- left inside the step
+      // code such a wait drains this step's own stores (hundreds of cycles) every time it is executed.
+#define EFA_PIN8(a) asm volatile("" : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(a[4]), "+v"(a[5]), "+v"(a[6]), "+v"(a[7]))
+      {
+        asm volatile("" : "+v"(mu), "+v"(xmv), "+v"(thr));
+        EFA_PIN8(band);
+      }
       EFA_BLOCKSTAMP(lane == 0, 0);
       for (int b = 0; b < nbands && ok; ++b) {
         const int r0 = kBand * b;
         const int s1 = (nb - r0 < kBand) ? nb - r0 : kBand;  // steps of this band
         if (b > 0) {  // the band's rows, current through the previous band, from the two G waves
-          ok = wait_gt(&ctl[cBandH], b - 1, false) && wait_gt(&ctl[cBandH + 1], b - 1, false);
+          if (!EFA_EXP(2048)) ok = wait_gt(&ctl[cBandH], b - 1, false) && wait_gt(&ctl[cBandH + 1], b - 1, false);
           if (!ok) break;
 #pragma unroll
           for (int s = 0; s < kBand; ++s) band[s] = G_s[(r0 + s) * kRowsWG + lane];
+          EFA_PIN8(band);
         }
         // (L^-1)[s][t] for this band, lane t holds column t (lanes >= 8 carry zeros): right-looking,
         // linv[s'] -= L[s'][s] linv[s] once row s is final

@@ -395,7 +395,7 @@ __global__ __launch_bounds__(kGT) void k_pipe_gram(const PipeArgs a) {
       // cancellation guard: an assimilated pivot whose G_kk fell below 1e-3 of its value at block start.  It is
       // only ACCUMULATED in the loop (one compare + two scalar ops per step) and acted upon after the block: a
       // tripped guard abandons the whole launch, so the numbers produced meanwhile are never used.
-      const double thr = my_asm ? 1e-3 * G_s[lane * kRowsWG + lane] : -1.0;
+      const double thr_ld = my_asm ? 1e-3 * G_s[lane * kRowsWG + lane] : -1.0;
       u64 bad = 0ull;
       bool bailed = false;
 #ifdef EFA_PIPE_BLOCKTIME
@@ -403,6 +403,11 @@ __global__ __launch_bounds__(kGT) void k_pipe_gram(const PipeArgs a) {
 #endif
       double g = G_s[lane];             // row 0
       double g1 = G_s[kRowsWG + lane];  // row 1
+      // values that came from LDS are pinned here: a wait left at their first use inside the step code would be
+      // executed every step and drain that step's own (exec-masked, hence uncounted) record stores
+      double thr_p = thr_ld;
+      asm volatile("" : "+v"(mu), "+v"(xmv), "+v"(thr_p), "+v"(g), "+v"(g1));
+      const double thr = thr_p;
       const bool gc = a.loc_mode != 0;
       // slow path of the hand-over (the helper is late): poll flag and row together
       auto wait_row = [&](int kk, double& r2) {

@@ -1,0 +1,35 @@
+"""Diagnostic: per-block times of the band leader (k_pipe_band).  Needs `make -C efa_xray_amd/csrc diag` and
+EFA_HIP_LIB=efa_xray_amd/libefa_hip_diag.so.   usage: band_blocktime.py [P] [debug bits] [gram option]"""
+import sys, os, ctypes
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+from efa_xray_amd import _lib
+ctx = _lib.get_context(0)
+M = 100
+P = int(sys.argv[1]) if len(sys.argv) > 1 else 1024
+bits = int(sys.argv[2]) if len(sys.argv) > 2 else 0
+gram = int(sys.argv[3]) if len(sys.argv) > 3 else 2
+rng = np.random.default_rng(0)
+ctx.set_option("path", 1); ctx.set_option("pipeline", 1); ctx.set_option("gram", gram); ctx.set_option("pipe_debug", 4 | bits)
+ctx.set_option("timing", 1)
+HX = rng.standard_normal((P, M)) * 3
+val = HX.mean(axis=1) + rng.standard_normal(P); err = np.ones(P); asm = np.ones(P, bool)
+for _ in range(3):
+    Yp = ctx.to_device(HX); ym = ctx.empty((P,))
+    ctx.form_perts(P, M, Yp, ym, Yp)
+    try:
+        ctx.obs_phase(M, P, ym, Yp, val, err, asm)
+    except Exception as e:
+        print("error", e)
+addr = ctx.get_option("pipe_dbg_addr")
+out = np.zeros((P, 8), dtype=np.uint64)
+_lib._check(ctx.lib, ctx.lib.efa_memcpy_d2h(ctx.handle, out.ctypes.data, ctypes.c_void_p(addr), out.nbytes))
+t = out.astype(np.int64)
+nb = P // 64
+piv = [t[64 * b, 1] - t[64 * b, 0] for b in range(1, nb)]
+blk = [t[64 * b, 2] - t[64 * b, 0] for b in range(1, nb)]
+pre = [t[64 * b, 0] - t[64 * b, 3] for b in range(1, nb)]
+print("bits %d gram %d kind %d obs_ms %.3f" % (bits, gram, ctx.get_option("phase_a_kind"), ctx.last_timing()["obs_ms"]))
+print("  pivot loop %6.0f cycles/step | pivot start -> last record forwarded %6.0f /step | last foreign record -> pivot start %6.0f cycles"
+      % (np.median(piv) / 64, np.median(blk) / 64, np.median(pre)))
+ctx.set_option("pipe_debug", 0); ctx.set_option("path", 0); ctx.set_option("gram", 2)
