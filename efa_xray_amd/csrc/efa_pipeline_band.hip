@@ -18,8 +18,8 @@
 //                the ob's scalars; per band the inverse of the band's unit lower triangular factor
 //                (ye_{r0+s} = y_{r0+s} - sum_{t<s} kb^{(t)}_{r0+s} ye_{r0+t}  <=>  YE = L^-1 Y).
 //   2 G waves    hold G as matrix-core accumulator tiles (two tile columns each) and apply a
-//                band's eight rank-one downdates as ONE rank-8 update per tile
-//                (v_mfma_f64_16x16x4_f64, A = gamma_s g^(s)_i, B = g^(s)_j); the tile row of the next band
+//                band's downdates as matrix-core updates per tile (v_mfma_f64_16x16x4_f64, from the step
+//                records alone: A = -G_ki, B = kb_j and A = -kb_i, B = t_j); the tile row of the next band
 //                goes first and is handed to the pivot wave through LDS.
 //   4 vector waves  park the band's 8 rows, form YE = L^-1 Y on the matrix cores (no ye_k -> ye_{k+1}
 //                chain across waves), and apply the band to all 64 rows as one rank-8 update
@@ -47,13 +47,17 @@ constexpr int PLg = kPipeLanes;  // lanes per row: same record layout as efa_pip
 constexpr int kRingG = 16;    // LDS ring slots for ye rows (two bands)
 constexpr int kPollG = 4;
 constexpr int kRowsWG = kPipeRowsPerWG;  // 64
-constexpr int kBand = 8;      // observations per band
+#ifndef EFA_BAND
+#define EFA_BAND 4
+#endif
+constexpr int kBand = EFA_BAND;  // observations per band (4 or 8)
+static_assert(kBand == 4 || kBand == 8, "band size");
 constexpr int kNBands = kRowsWG / kBand;
 static_assert(PLg == 4 && kRowsWG == 64, "layout assumptions of the band kernel");
 
 // control words (ints in LDS)
 enum { cReady = 0, cBail = 1, cSReady = 2, cFwd = 3, cProg = 4 /* ..7 */, cBandH = 8 /* ..9 */, cLinv = 10, cPark = 11, cYe = 12 };
-constexpr int kScStride = 8;  // doubles per step in the pivot's scalar records: innov, rden, beta, active, prior mean, prior var, gamma
+constexpr int kScStride = 4;  // doubles per ob: rden, beta (latched by the pivot wave), innov, active (added by the forwarder): the record's scalars
 
 __device__ __forceinline__ u64 g_traj_load(const u64* p) {
   return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -95,7 +99,7 @@ struct BandShape {
   static constexpr int TS = PAD + kTrajScalars;
   static constexpr int SP = PAD + ((2 - PAD % 32) + 32) % 32;  // park tile row stride == 2 (mod 32): conflict-free operand reads
   static constexpr int SPB = PAD + ((16 - PAD % 32) + 32) % 32;  // band tile row stride == 16 (mod 32): conflict-free B-operand reads
-  static constexpr int UREG = (kRowsWG * SP > kRowsWG * (2 * kRowsWG + kScStride)) ? kRowsWG * SP : kRowsWG * (2 * kRowsWG + kScStride);
+  static constexpr int UREG = (kRowsWG * SP > kRowsWG * (2 * kRowsWG + kScStride + 1)) ? kRowsWG * SP : kRowsWG * (2 * kRowsWG + kScStride + 1);
   static constexpr int kLinv = kNBands * kBand * 16;  // L^-1 of every band, [band][t][16]: A-operand order
   static constexpr int kYb = 2 * kBand * SPB;         // the band's parked rows, double buffered
   static size_t lds_doubles() { return (size_t)kRingG * TS + kRowsWG * kRowsWG + UREG + 2 * kRowsWG + kLinv + kYb; }
@@ -118,7 +122,8 @@ __global__ __launch_bounds__(kGT) void k_pipe_band(const PipeArgs a) {
   int* ctl = reinterpret_cast<int*>(Yb + Sh::kYb);  // [32]
   double* Yt = U;
   double2* s_gk = reinterpret_cast<double2*>(U);  // [step][row] = {G_kj, kb_j}
-  double* s_sc = U + 2 * kRowsWG * kRowsWG;       // [step][8]
+  double* s_sc = U + 2 * kRowsWG * kRowsWG;       // [ob][4]  rden, beta | innov, active: the four scalars of the ob's record
+  double* s_var = s_sc + kRowsWG * kScStride;     // [ob]     prior variance (np.var, ddof 0) latched by the pivot wave
 
   const int tid = threadIdx.x;
   // wave roles: 0-3 vector, 4 pivot, 5-6 G waves, 7 loader
@@ -279,6 +284,14 @@ __global__ __launch_bounds__(kGT) void k_pipe_band(const PipeArgs a) {
       form_gram();
       __syncthreads();  // B2: G is complete
       barriers_left = 1;
+      // This wave also carries the obs-space MEANS of the block's 64 rows (lane j = row j) and everything that
+      // hangs on them -- innovation, mean update (:85, :130), the obs' diagnostics -- from the pivot wave's records:
+      // none of it is on the serial chain, and every instruction the pivot wave does not issue shortens a step.
+      double xmv = pm[kRowsWG + lane];
+      const bool f_ob = lane < nb;
+      const double val_l = f_ob ? a.ob_value[own0 + lane] : 0.0;
+      const u64 asm_mask = __ballot(f_ob ? (a.ob_assim[own0 + lane] != 0) : false);
+      double l_xm = 0.0;
       for (int b = 0; b < nbands && !failed; ++b) {
         // the band's ye rows are in the ring once every vector wave has added its tiles (4 per band)
         if (!wait_gt(&ctl[cYe], 4 * (b + 1) - 1, true)) {
@@ -290,41 +303,60 @@ __global__ __launch_bounds__(kGT) void k_pipe_band(const PipeArgs a) {
           const int st = kBand * b + s;
           const long f = own0 + st;
           const double* slot = ring + (size_t)(f % kRingG) * TS;
-          const double* sc = s_sc + (size_t)st * kScStride;
+          const double2 gk = s_gk[st * kRowsWG + lane];                        // G_kj, kb_j of this lane's row
+          const double rden = s_sc[(size_t)st * kScStride];
+          const bool act = ((asm_mask >> st) & 1) != 0;
+          const double xmk = rl(xmv, st);
+          const double innov = rl(val_l, st) - xmk;                            // :85
+          const double kc = gk.x * rM1;                                        // :95
+          const double km = act ? kc * rden : 0.0;                             // :119
+          xmv = xmv + km * innov;                                              // :130
+          l_xm = (lane == st) ? xmk : l_xm;                                    // this lane's ob: its prior mean (:66)
+          // record = ye, then the four scalars the followers read: rden, beta, innov, active
           u64* rec = a.traj + (size_t)f * TS;
+          const double actv = act ? 1.0 : 0.0;
 #pragma unroll
           for (int e = 0; e < EPL; ++e) {
-            const int idx = lane + 64 * e;  // record = ye, then 8 scalars of which the followers read [2..5]
-            const int si = idx - PAD - 2;
-            if (idx < TS) g_traj_store(rec + idx, idx < PAD ? slot[idx] : ((si >= 0 && si < 4) ? sc[si] : 0.0));
-          }
-          if (lane == 0) g_ctl_set(&ctl[cFwd], (int)f);
-          // the ob's diagnostics and sweep coefficients, derived from the pivot's record: the same operations in
-          // the same order as the pivot's own lane k (km = kc rden, kc = G_kk/(M-1)); the ob's own row is scaled
-          // by (1 - kb_k)  (:144-149)
-          if (lane == 0) {
-            const double2 s01 = *reinterpret_cast<const double2*>(sc);      // innov, rden
-            const double2 s23 = *reinterpret_cast<const double2*>(sc + 2);  // beta, active
-            const double2 s45 = *reinterpret_cast<const double2*>(sc + 4);  // prior mean, prior var
-            const double2 gk = s_gk[st * kRowsWG + st];                     // G_kk, kb_k
-            const bool act = s23.y != 0.0;
-            a.prior_mean[f] = s45.x;                                        // :66
-            a.prior_var[f] = s45.y;                                         // :70
-            double* ck = a.coef + (size_t)f * kCoefStride;
-            ck[0] = act ? s01.x : 0.0;
-            ck[1] = act ? s01.y : 0.0;
-            ck[2] = act ? s23.x : 0.0;
-            ck[3] = act ? 1.0 : 0.0;
-            a.assimilated[f] = act ? 1 : 0;                                 // :74-76, :149
-            if (act) {
-              const double km = (gk.x * rM1) * s01.y;                       // :95, :119
-              const double fsc = 1.0 - gk.y;
-              a.post_mean[f] = s45.x + km * s01.x;                          // :130
-              a.post_var[f] = (fsc * fsc) * s45.y;
+            const int idx = lane + 64 * e;
+            if (64 * (e + 1) <= PAD) {
+              g_traj_store(rec + idx, slot[idx]);
+            } else if (idx < TS) {
+              // one LDS read per lane (ye, or rden / beta where the pivot wave latched them), then two register
+              // selects for innov and active: values of this wave, so no hand-off between lanes is involved
+              const int sj = idx - PAD;
+              const int off = (sj < 0) ? (int)(slot - lds) + idx : (int)(s_sc - lds) + st * kScStride + (sj < 1 ? 0 : 1);
+              double v = lds[off];
+              v = (sj == 2) ? innov : v;
+              v = (sj >= 3) ? actv : v;
+              g_traj_store(rec + idx, v);
             }
           }
+          if (lane == 0) g_ctl_set(&ctl[cFwd], (int)f);
         }
       }
+      // The obs' diagnostics and sweep coefficients, once per block and one ob per lane, from what is in LDS anyway:
+      // km of the ob's own row is kc rden with kc = G_kk/(M-1), and that row is scaled by (1 - kb_k)  (:144-149).
+      if (!failed && f_ob) {
+        const long f = own0 + lane;
+        const double2 gk = s_gk[lane * kRowsWG + lane];                        // G_kk, kb_k at the ob's own step
+        const double2 rb = *reinterpret_cast<const double2*>(s_sc + (size_t)lane * kScStride);  // rden, beta
+        const double var = s_var[lane];
+        const bool act = ((asm_mask >> lane) & 1) != 0;
+        const double innov = val_l - l_xm;                                     // :85
+        a.prior_mean[f] = l_xm;                                                // :66
+        a.prior_var[f] = var;                                                  // :70
+        double* ck = a.coef + (size_t)f * kCoefStride;
+        *reinterpret_cast<double2*>(ck) = make_double2(act ? innov : 0.0, act ? rb.x : 0.0);
+        *reinterpret_cast<double2*>(ck + 2) = make_double2(act ? rb.y : 0.0, act ? 1.0 : 0.0);
+        a.assimilated[f] = act ? 1 : 0;                                        // :74-76, :149
+        if (act) {
+          const double km = (gk.x * rM1) * rb.x;                               // :95, :119
+          const double fsc = 1.0 - gk.y;
+          a.post_mean[f] = l_xm + km * innov;                                  // :130
+          a.post_var[f] = (fsc * fsc) * var;
+        }
+      }
+      pm[kRowsWG + lane] = xmv;  // obs-space means of all 64 rows after the block, back to the vector waves
       EFA_BLOCKSTAMP(lane == 0, 2);
       __syncthreads();  // B3: done with the pivot's records
       barriers_left = 0;
@@ -343,7 +375,6 @@ __global__ __launch_bounds__(kGT) void k_pipe_band(const PipeArgs a) {
     // the block's ob constants are fetched now, while the wave waits for its block anyway
     const bool pre_ob = lane < nb;
     const double pre_err = (wave == kVW && pre_ob) ? a.ob_error[own0 + lane] : 1.0;
-    const double pre_val = (wave == kVW && pre_ob) ? a.ob_value[own0 + lane] : 0.0;
     const bool pre_asm = (wave == kVW && pre_ob) ? (a.ob_assim[own0 + lane] != 0) : false;
     const double pre_sq = sqrt(pre_err);
     __syncthreads();  // B1
@@ -355,9 +386,9 @@ __global__ __launch_bounds__(kGT) void k_pipe_band(const PipeArgs a) {
       // ob's lane (v_readlane), the band's later rows are downdated in registers, nothing is read from LDS
       // inside a band, and the step's record is written at its end.  Gain chain as in efa_pipeline_gram.hip:
       //   kdenom -> q0 = rsq(kdenom) -> { Newton step of q  ||  beta0 = 1/(1 + sqrt(err) q0) } -> beta
-      double mu = pm[lane], xmv = pm[kRowsWG + lane];
+      double mu = pm[lane];
       const bool my_asm = pre_asm;
-      const double err_l = pre_err, sq_l = pre_sq, val_l = pre_val;
+      const double err_l = pre_err, sq_l = pre_sq;
       const u64 asm_mask = __ballot(my_asm);
       // cancellation guard: an assimilated pivot whose G_kk fell below 1e-3 of its value at block start; accumulated
       // in the loop, acted upon after the block (a tripped guard abandons the launch: nothing produced meanwhile is used)
@@ -367,14 +398,12 @@ __global__ __launch_bounds__(kGT) void k_pipe_band(const PipeArgs a) {
       double band[kBand];
 #pragma unroll
       for (int s = 0; s < kBand; ++s) band[s] = G_s[s * kRowsWG + lane];
-      // Every value that came from LDS is pinned HERE: the compiler waits for a load where its result is first used,
-      // with an lgkmcnt count that treats the exec-masked record stores of a step as absent -- left inside the step
-      // code such a wait drains this step's own stores (hundreds of cycles) every time it is executed.
-#define EFA_PIN8(a) asm volatile("" : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(a[4]), "+v"(a[5]), "+v"(a[6]), "+v"(a[7]))
-      {
-        asm volatile("" : "+v"(mu), "+v"(xmv), "+v"(thr));
-        EFA_PIN8(band);
-      }
+      // Every value that came from LDS is pinned HERE: the compiler waits for a load where its result is first used;
+      // left inside the step code such a wait would be executed every step.
+#define EFA_PIN_BAND(a) _Pragma("unroll") for (int pin_i = 0; pin_i < kBand; ++pin_i) asm volatile("" : "+v"(a[pin_i]))
+      asm volatile("" : "+v"(mu), "+v"(thr));
+      EFA_PIN_BAND(band);
+      double l_rd = 0.0, l_be = 0.0, l_var = 0.0;  // this lane's ob: 1/kdenom, beta, prior variance (latched at its step)
       EFA_BLOCKSTAMP(lane == 0, 0);
       for (int b = 0; b < nbands && ok; ++b) {
         const int r0 = kBand * b;
@@ -384,7 +413,7 @@ __global__ __launch_bounds__(kGT) void k_pipe_band(const PipeArgs a) {
           if (!ok) break;
 #pragma unroll
           for (int s = 0; s < kBand; ++s) band[s] = G_s[(r0 + s) * kRowsWG + lane];
-          EFA_PIN8(band);
+          EFA_PIN_BAND(band);
         }
         // (L^-1)[s][t] for this band, lane t holds column t (lanes >= 8 carry zeros): right-looking,
         // linv[s'] -= L[s'][s] linv[s] once row s is final
@@ -398,8 +427,8 @@ __global__ __launch_bounds__(kGT) void k_pipe_band(const PipeArgs a) {
             const double g = band[s];
             const bool act = ((asm_mask >> kk) & 1) != 0;
             bad |= __ballot(!(g > thr)) & (1ull << kk);
-            const double Gkk = rl(g, kk), muk = rl(mu, kk), xmk = rl(xmv, kk);
-            const double errk = rl(err_l, kk), sqk = rl(sq_l, kk), valk = rl(val_l, kk);
+            const double Gkk = rl(g, kk), muk = rl(mu, kk);
+            const double errk = rl(err_l, kk), sqk = rl(sq_l, kk);
             const double mu2 = muk * muk;
             const double kdenom = __builtin_fma(Gkk, invM, errk - mu2);   // var + err  (:69, :91)
             const double q0 = __builtin_amdgcn_rsq(kdenom);
@@ -416,33 +445,27 @@ __global__ __launch_bounds__(kGT) void k_pipe_band(const PipeArgs a) {
             const double kc = g * rM1;                                    // :95
             const double km = act ? kc * rden : 0.0;                      // :119
             const double kb = beta * km;                                  // :136
-            const double innov = valk - xmk;                              // :85
-            xmv = xmv + km * innov;                                       // :130
             mu = __builtin_fma(-kb, muk, mu);
-            const double t = __builtin_fma(-kb, Gkk, g);
-            // the rank-one downdate of G by this step is gamma g g^T with gamma = c (2 - c G_kk), c = kb_j / G_kj:
-            // what the G waves apply to their tiles (the band's own rows use the two-term form below)
+            // this step's rank-one downdate of G is gamma g g^T, gamma = c (2 - c G_kk) with c = kb_j / G_kj: the form
+            // the band's later rows (and L, below) use -- one v_readlane pair per row instead of two
             const double cc = act ? (beta * rden) * rM1 : 0.0;
             const double gam = cc * __builtin_fma(-cc, Gkk, 2.0);
 #pragma unroll
             for (int s2 = s + 1; s2 < kBand; ++s2) {
-              const double gi = rl(g, r0 + s2), ai = rl(kb, r0 + s2);     // G_k,i and kb_i of row i = r0 + s2
-              band[s2] = __builtin_fma(-ai, t, __builtin_fma(-kb, gi, band[s2]));
-              linv[s2] = __builtin_fma(-ai, linv[s], linv[s2]);           // L[s2][s] = kb_i
+              const double gi = rl(g, r0 + s2);                           // G_k,i of row i = r0 + s2
+              band[s2] = __builtin_fma(-(gam * gi), g, band[s2]);
+              linv[s2] = __builtin_fma(-(cc * gi), linv[s], linv[s2]);    // L[s2][s] = kb_i = c G_k,i
             }
-            // the step's record: {G_kj, kb_j} per row, then (lane 0) the scalars and the flag
-            s_gk[kk * kRowsWG + lane] = make_double2(g, kb);
-            if (lane == 0) {
-              double2* sc = reinterpret_cast<double2*>(s_sc + (size_t)kk * kScStride);
-              sc[0] = make_double2(innov, rden);
-              sc[1] = make_double2(beta, act ? 1.0 : 0.0);
-              sc[2] = make_double2(xmk, __builtin_fma(Gkk, invM, -mu2));   // prior mean (:66), np.var ddof = 0 (:69, :70)
-              sc[3] = make_double2(gam, 0.0);
-              g_ctl_set(&ctl[cSReady], kk + 1);
-            }
+            const bool mine = lane == kk;
+            l_rd = mine ? rden : l_rd;
+            l_be = mine ? beta : l_be;
+            l_var = mine ? __builtin_fma(Gkk, invM, -mu2) : l_var;        // np.var, ddof = 0 (:69, :70)
+            s_gk[kk * kRowsWG + lane] = make_double2(g, kb);              // the step's record: {G_kj, kb_j} per row
           }
         }
-        // L^-1 of the band for the vector waves: LinvA[b][t][s], zero where s < t or s >= 8
+        // per band: the latched scalars of the obs done so far, L^-1 (LinvA[b][t][s], zero where s < t or s >= 8), flags
+        *reinterpret_cast<double2*>(s_sc + (size_t)lane * kScStride) = make_double2(l_rd, l_be);
+        s_var[lane] = l_var;
         if (lane < kBand) {
           double* dst = LinvA + ((size_t)b * kBand + lane) * 16;
 #pragma unroll
@@ -450,7 +473,10 @@ __global__ __launch_bounds__(kGT) void k_pipe_band(const PipeArgs a) {
 #pragma unroll
           for (int s = kBand; s < 16; ++s) dst[s] = 0.0;
         }
-        if (lane == 0) g_ctl_set(&ctl[cLinv], b + 1);
+        if (lane == 0) {
+          g_ctl_set(&ctl[cSReady], r0 + s1);
+          g_ctl_set(&ctl[cLinv], b + 1);
+        }
       }
       if (ok && bad != 0ull) {  // the downdate may have cancelled: abandon the launch (status[2]: the host re-runs
         if (lane == 0) {        // Phase A with the vector-chain kernel)
@@ -459,14 +485,13 @@ __global__ __launch_bounds__(kGT) void k_pipe_band(const PipeArgs a) {
         }
       }
       EFA_BLOCKSTAMP(lane == 0, 1);
-      pm[kRowsWG + lane] = xmv;  // obs-space means of all 64 rows after the block, back to the vector waves
       __syncthreads();  // B3
       return;
     }
     // ---------------- G waves: G as accumulator tiles, one rank-8 update per band ----------------
     // G wave h holds tile columns J = 2h, 2h+1 of the 4 x 4 tile grid: acc[I][jj][v] in lane l is
     // G[16 I + 4 v + l/16][16 (2h + jj) + l%16].  After band b (steps r0 .. r0+s1-1):
-    //   G -= sum_s gamma_s g^(s) g^(s)^T  ==  A B with A[i][s] = gamma_s g^(s)_i, B[s][j] = g^(s)_j
+    //   G_ij -= sum_s kb^(s)_j G^(s)_ki + kb^(s)_i t^(s)_j,   t_j = G_kj - kb_j G_kk   (what y_i -= kb_i ye_k does to the dots)
     // Only tile rows that still contain rows of later bands are kept current, the tile row of the next band
     // first: its 8 rows go back to G_s for the pivot wave.
     const int h = wave - kVW - 1;  // 0, 1
@@ -481,33 +506,44 @@ __global__ __launch_bounds__(kGT) void k_pipe_band(const PipeArgs a) {
     for (int b = 0; b + 1 < nbands; ++b) {  // nothing follows the last band
       const int r0 = kBand * b;
       if (!wait_gt(&ctl[cSReady], r0 + kBand - 1, false)) break;  // (a band before the last one is always full)
-      // B operands: g^(s)_j of this wave's 32 columns, two K slices of four steps
-      double bop[2][2];
+      // From the records {G_kj, kb_j} alone: G_ij -= kb_j G_ki + kb_i (G_kj - kb_j G_kk), two products per K slice of
+      // four steps: (A1 = -G_ki, B1 = kb_j) and (A2 = -kb_i, B2 = t_j).  B operands of this wave's 32 columns:
+      double b1[kBand / 4][2], b2[kBand / 4][2];
 #pragma unroll
-      for (int q = 0; q < 2; ++q)
+      for (int q = 0; q < kBand / 4; ++q) {
+        const int st = r0 + 4 * q + lr;                       // this lane's K slot: step st
+        const double Gkk = s_gk[st * kRowsWG + st].x;
 #pragma unroll
-        for (int jj = 0; jj < 2; ++jj) bop[q][jj] = s_gk[(r0 + 4 * q + lr) * kRowsWG + 16 * (2 * h + jj) + lc].x;
-      double gam[2];
-#pragma unroll
-      for (int q = 0; q < 2; ++q) gam[q] = s_sc[(size_t)(r0 + 4 * q + lr) * kScStride + 6];
+        for (int jj = 0; jj < 2; ++jj) {
+          const double2 r = s_gk[st * kRowsWG + 16 * (2 * h + jj) + lc];
+          b1[q][jj] = r.y;
+          b2[q][jj] = __builtin_fma(-r.y, Gkk, r.x);
+        }
+      }
       const int Inext = (r0 + kBand) >> 4;  // tile row of the next band
       auto update_row = [&](auto Itag) {
         constexpr int I = decltype(Itag)::value;
 #pragma unroll
-        for (int q = 0; q < 2; ++q) {
-          const double av = -gam[q] * s_gk[(r0 + 4 * q + lr) * kRowsWG + 16 * I + lc].x;  // A[i = lc][s = lr]
+        for (int q = 0; q < kBand / 4; ++q) {
+          const double2 r = s_gk[(r0 + 4 * q + lr) * kRowsWG + 16 * I + lc];  // A[i = lc][s = lr]
 #pragma unroll
-          for (int jj = 0; jj < 2; ++jj) acc[I][jj] = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bop[q][jj], acc[I][jj], 0, 0, 0);
+          for (int jj = 0; jj < 2; ++jj) {
+            acc[I][jj] = __builtin_amdgcn_mfma_f64_16x16x4f64(-r.x, b1[q][jj], acc[I][jj], 0, 0, 0);
+            acc[I][jj] = __builtin_amdgcn_mfma_f64_16x16x4f64(-r.y, b2[q][jj], acc[I][jj], 0, 0, 0);
+          }
         }
       };
-      auto hand_over = [&](auto Itag) {  // rows r0+8 .. r0+15 of tile row I (registers v0, v0+1) back to G_s
+      auto hand_over = [&](auto Itag) {  // the next band's rows of tile row I (registers v0 .. v0 + kBand/4 - 1) back to G_s
         constexpr int I = decltype(Itag)::value;
-        const int v0 = ((r0 + kBand) & 15) >> 2;  // 0 or 2
+        const int v0 = ((r0 + kBand) & 15) >> 2;
 #pragma unroll
         for (int jj = 0; jj < 2; ++jj) {
-          double* dst = G_s + (size_t)(16 * I + 4 * v0 + lr) * kRowsWG + 16 * (2 * h + jj) + lc;
-          dst[0] = (v0 == 0) ? acc[I][jj][0] : acc[I][jj][2];
-          dst[4 * kRowsWG] = (v0 == 0) ? acc[I][jj][1] : acc[I][jj][3];
+#pragma unroll
+          for (int vv = 0; vv < kBand / 4; ++vv) {
+            const int v = v0 + vv;
+            const double val = (v == 0) ? acc[I][jj][0] : (v == 1) ? acc[I][jj][1] : (v == 2) ? acc[I][jj][2] : acc[I][jj][3];
+            G_s[(size_t)(16 * I + 4 * v + lr) * kRowsWG + 16 * (2 * h + jj) + lc] = val;
+          }
         }
       };
       switch (Inext) {  // the next band's tile row first, handed over at once
@@ -576,21 +612,24 @@ __global__ __launch_bounds__(kGT) void k_pipe_band(const PipeArgs a) {
         const int r0 = kBand * b;
         const int s1 = (nb - r0 < kBand) ? nb - r0 : kBand;
         double* yb = Yb + (size_t)(b & 1) * kBand * SPB;
-        // (1) park the band's rows (current through the previous band).  Row r0 + s is block row 4 rho + w with
-        //     rho = 2 b + s/4, w = s%4: this wave holds s = w and s = 4 + w in register v = b/2, lane rows
-        //     lr = 2 (b%2) and 2 (b%2) + 1.
-        if ((lr >> 1) == (b & 1)) {
-          double* dst = yb + (size_t)(4 * (lr & 1) + wave) * SPB + lc;
-          switch (b >> 1) {
+        // (1) park the band's rows (current through the previous band).  Band row s = 4 i + w is block row 4 rho + w
+        //     with rho = r0/4 + i: this wave holds it in register v = rho/4, lane row lr = rho%4.
+#pragma unroll
+        for (int i = 0; i < kBand / 4; ++i) {
+          const int rho = (r0 >> 2) + i;
+          if (lr == (rho & 3)) {
+            double* dst = yb + (size_t)(4 * i + wave) * SPB + lc;
+            switch (rho >> 2) {
 #define EFA_PARK_CASE(V)                                           \
   case V:                                                          \
     _Pragma("unroll") for (int J = 0; J < NJ; ++J) dst[16 * J] = xt[J][V]; \
     break;
-            EFA_PARK_CASE(0)
-            EFA_PARK_CASE(1)
-            EFA_PARK_CASE(2)
-            EFA_PARK_CASE(3)
+              EFA_PARK_CASE(0)
+              EFA_PARK_CASE(1)
+              EFA_PARK_CASE(2)
+              EFA_PARK_CASE(3)
 #undef EFA_PARK_CASE
+            }
           }
         }
         if (lane == 0) __hip_atomic_fetch_add(&ctl[cPark], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
@@ -599,9 +638,9 @@ __global__ __launch_bounds__(kGT) void k_pipe_band(const PipeArgs a) {
           bailed = true;
           break;
         }
-        // ring slots of this band are those of band b-2: every consumer must be through with them
-        if (b >= 2) {
-          const int need = (int)(own0 + kBand * (b - 2) + kBand - 1);
+        // ring slots of this band are those of the band kRingG obs earlier: every consumer must be through with them
+        if (b >= kRingG / kBand) {
+          const int need = (int)(own0 + kBand * (b - kRingG / kBand) + kBand - 1);
           while (min_prog() < need) {
             if (g_ctl(&ctl[cBail]) != 0 || --budget <= 0 || ((budget & 15) == 0 && EFA_TIMED_OUT())) {
               bailed = true;
@@ -612,17 +651,20 @@ __global__ __launch_bounds__(kGT) void k_pipe_band(const PipeArgs a) {
         }
         {
           const double* la = LinvA + (size_t)b * kBand * 16;
-          const double a0 = la[(size_t)lr * 16 + lc], a1 = la[(size_t)(4 + lr) * 16 + lc];  // A[s = lc][t = 4 q + lr]
+          double aop[kBand / 4];
+#pragma unroll
+          for (int q = 0; q < kBand / 4; ++q) aop[q] = la[(size_t)(4 * q + lr) * 16 + lc];  // A[s = lc][t = 4 q + lr]
 #pragma unroll
           for (int jt = 0; jt < 2; ++jt) {
             const int J = wave + 4 * jt;  // this wave's column tiles
             if (J < NJ) {
               v4f64 ye = {0.0, 0.0, 0.0, 0.0};
-              ye = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, yb[(size_t)lr * SPB + 16 * J + lc], ye, 0, 0, 0);
-              ye = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, yb[(size_t)(4 + lr) * SPB + 16 * J + lc], ye, 0, 0, 0);
-              // D[s = 4 v + lr][col = lc]: rows s < 8 are ye_{r0+s}
 #pragma unroll
-              for (int v = 0; v < 2; ++v) {
+              for (int q = 0; q < kBand / 4; ++q)
+                ye = __builtin_amdgcn_mfma_f64_16x16x4f64(aop[q], yb[(size_t)(4 * q + lr) * SPB + 16 * J + lc], ye, 0, 0, 0);
+              // D[s = 4 v + lr][col = lc]: rows s < kBand are ye_{r0+s}
+#pragma unroll
+              for (int v = 0; v < kBand / 4; ++v) {
                 const int s = 4 * v + lr;
                 if (16 * J + lc < PAD) ring[(size_t)((own0 + r0 + s) % kRingG) * TS + 16 * J + lc] = ye[v];
               }
@@ -636,7 +678,7 @@ __global__ __launch_bounds__(kGT) void k_pipe_band(const PipeArgs a) {
           break;
         }
 #pragma unroll
-        for (int q = 0; q < 2; ++q) {
+        for (int q = 0; q < kBand / 4; ++q) {
           const int st = r0 + 4 * q + lr;        // this lane's K slice: step st
           const bool valid = (4 * q + lr) < s1;
           double av = s_gk[(valid ? st : r0) * kRowsWG + 4 * lc + wave].y;  // A[rho = lc][s]: kb of block row 4 rho + w
@@ -677,15 +719,15 @@ __global__ __launch_bounds__(kGT) void k_pipe_band(const PipeArgs a) {
     const double* slot = ring + (size_t)(k % kRingG) * TS;
     double y[2 * NC];
     lds_read_row<PLg, NC>(slot, j, y);
-    const double2 s23 = *reinterpret_cast<const double2*>(slot + PAD + 2);  // innov, rden
-    const double2 s45 = *reinterpret_cast<const double2*>(slot + PAD + 4);  // beta, active
+    const double2 s01 = *reinterpret_cast<const double2*>(slot + PAD);      // rden, beta
+    const double2 s23 = *reinterpret_cast<const double2*>(slot + PAD + 2);  // innov, active
     if (lane == 0) g_ctl_set(&ctl[cProg + wave], (int)k);
-    if (__builtin_amdgcn_readfirstlane((int)(s45.y != 0.0)) != 0) {
+    if (__builtin_amdgcn_readfirstlane((int)(s23.y != 0.0)) != 0) {
       const double dot = group_dot<PLg, NC>(x, y);
       const double kc = dot * rM1;                        // :95
-      const double km = kc * s23.y;                       // :119
+      const double km = kc * s01.x;                       // :119
       xm = xm + km * s23.x;                               // :130
-      const double kb = s45.x * km;                       // :136
+      const double kb = s01.y * km;                       // :136
 #pragma unroll
       for (int c = 0; c < 2 * NC; ++c) x[c] = __builtin_fma(-kb, y[c], x[c]);  // :141
     }
@@ -724,7 +766,7 @@ bool pipeline_band_supported(int M, long R, int loc_mode) {
   const int nc = (M + 2 * PLg - 1) / (2 * PLg);
   const int pad = 2 * PLg * nc, ts = pad + kTrajScalars;
   const int sp = pad + ((2 - pad % 32) + 32) % 32, spb = pad + ((16 - pad % 32) + 32) % 32;
-  const size_t ureg = (size_t)kRowsWG * (sp > 2 * kRowsWG + kScStride ? sp : 2 * kRowsWG + kScStride);
+  const size_t ureg = (size_t)kRowsWG * (sp > 2 * kRowsWG + kScStride + 1 ? sp : 2 * kRowsWG + kScStride + 1);
   const size_t dbl = (size_t)kRingG * ts + kRowsWG * kRowsWG + ureg + 2 * kRowsWG + kNBands * kBand * 16 + 2 * kBand * spb;
   return dbl * 8 + 128 <= 160 * 1024;
 }
