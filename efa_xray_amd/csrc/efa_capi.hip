@@ -239,7 +239,9 @@ int obs_phase(efa_ctx* c, int M, long P, double* ym_dev, double* Yp_dev, const d
   bool done_by_pipeline = false;
   const bool tw_fits = (loc_mode != EFA_LOC_GC) || ((size_t)P * (size_t)R * sizeof(double) <= ((size_t)3 << 30));
   if (c->use_pipeline && pipeline_supported(M, R) && tw_fits) {
-    const long TS = traj_stride(M);
+    // the band kernel pads a record's ye row to its own lane layout: buffers are sized for the longer record
+    const long TS_std = traj_stride(M), TS_band = band_traj_stride(M);
+    const long TS = TS_std > TS_band ? TS_std : TS_band;
     EFA_TRY(c->traj.reserve((size_t)P * TS * sizeof(unsigned long long)));
     EFA_TRY(c->status.reserve(3 * sizeof(int)));
     EFA_HIP(launch_fill_u64(c->traj.as<unsigned long long>(), (size_t)P * TS, kTrajSentinel, s));
@@ -301,7 +303,7 @@ int obs_phase(efa_ctx* c, int M, long P, double* ym_dev, double* Yp_dev, const d
       if (st[0] == 0 && st[1] == 0) {
         done_by_pipeline = true;
         c->ye_ptr = reinterpret_cast<const double*>(c->traj.p);
-        c->ye_stride = TS;
+        c->ye_stride = (kind == 4) ? TS_band : TS_std;
         c->phase_a_kind = kind;
       } else {
         EFA_HIP(hipMemcpyAsync(Yw, Yp_dev, (size_t)P * M * sizeof(double), hipMemcpyDeviceToDevice, s));

@@ -114,6 +114,7 @@ hipError_t launch_pipeline_gram(const PipeArgs& a, hipStream_t s);  // efa_pipel
 bool pipeline_gram_supported(int M, long R, int loc_mode);
 hipError_t launch_pipeline_band(const PipeArgs& a, hipStream_t s);  // efa_pipeline_band.hip (unlocalised cycles)
 bool pipeline_band_supported(int M, long R, int loc_mode);
+long band_traj_stride(int M);  // doubles per trajectory record as k_pipe_band lays them out (its rows are padded to its own lane layout)
 hipError_t launch_fill_u64(unsigned long long* p, size_t n, unsigned long long v, hipStream_t s);
 hipError_t launch_obs_taper_matrix(long P, long R, const double* ob_lat, const double* ob_lon,
                                    const double* ob_hw, double* tw, hipStream_t s);

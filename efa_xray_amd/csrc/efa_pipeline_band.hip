@@ -56,7 +56,8 @@ constexpr int kNBands = kRowsWG / kBand;
 static_assert(PLg == 4 && kRowsWG == 64, "layout assumptions of the band kernel");
 
 // control words (ints in LDS)
-enum { cReady = 0, cBail = 1, cSReady = 2, cFwd = 3, cProg = 4 /* ..7 */, cBandH = 8 /* ..9 */, cLinv = 10, cPark = 11, cYe = 12 };
+enum { cReady = 0, cBail = 1, cSReady = 2, cFwd = 3, cProg = 4 /* ..7 */, cBandH = 8 /* ..9 */, cLinv = 10, cPark = 11, cYe = 12, cHalf = 13 };
+constexpr int kEarly = kBand / 2;  // steps of a band the G waves have applied to the next band's rows when they hand them over
 constexpr int kScStride = 4;  // doubles per ob: rden, beta (latched by the pivot wave), innov, active (added by the forwarder): the record's scalars
 
 __device__ __forceinline__ u64 g_traj_load(const u64* p) {
@@ -382,6 +383,7 @@ __global__ __launch_bounds__(kGT) void k_pipe_band(const PipeArgs a) {
     __syncthreads();  // B2
     if (wave == kVW) {
       // ---------------- pivot wave: lane j <-> column j of G ----------------
+      __builtin_amdgcn_s_setprio(3);  // the serial chain: ahead of the vector wave that shares its SIMD
       // One wave issues in order, so what a step costs is its instruction count: per-ob constants live in the
       // ob's lane (v_readlane), the band's later rows are downdated in registers, nothing is read from LDS
       // inside a band, and the step's record is written at its end.  Gain chain as in efa_pipeline_gram.hip:
@@ -404,6 +406,9 @@ __global__ __launch_bounds__(kGT) void k_pipe_band(const PipeArgs a) {
       asm volatile("" : "+v"(mu), "+v"(thr));
       EFA_PIN_BAND(band);
       double l_rd = 0.0, l_be = 0.0, l_var = 0.0;  // this lane's ob: 1/kdenom, beta, prior variance (latched at its step)
+      double gprev[kBand - kEarly], gamprev[kBand - kEarly];  // rows and gammas of the previous band's late steps
+#pragma unroll
+      for (int o = 0; o < kBand - kEarly; ++o) gprev[o] = gamprev[o] = 0.0;
       EFA_BLOCKSTAMP(lane == 0, 0);
       for (int b = 0; b < nbands && ok; ++b) {
         const int r0 = kBand * b;
@@ -414,6 +419,16 @@ __global__ __launch_bounds__(kGT) void k_pipe_band(const PipeArgs a) {
 #pragma unroll
           for (int s = 0; s < kBand; ++s) band[s] = G_s[(r0 + s) * kRowsWG + lane];
           EFA_PIN_BAND(band);
+          // the G waves handed these rows over EARLY, current through the first kEarly steps of the previous band
+          // (so that this wave never waits for them); the rest of that band is applied here, in order
+#pragma unroll
+          for (int o = 0; o < kBand - kEarly; ++o) {
+#pragma unroll
+            for (int s2 = 0; s2 < kBand; ++s2) {
+              const double gi = rl(gprev[o], r0 + s2);
+              band[s2] = __builtin_fma(-(gamprev[o] * gi), gprev[o], band[s2]);
+            }
+          }
         }
         // (L^-1)[s][t] for this band, lane t holds column t (lanes >= 8 carry zeros): right-looking,
         // linv[s'] -= L[s'][s] linv[s] once row s is final
@@ -461,6 +476,11 @@ __global__ __launch_bounds__(kGT) void k_pipe_band(const PipeArgs a) {
             l_be = mine ? beta : l_be;
             l_var = mine ? __builtin_fma(Gkk, invM, -mu2) : l_var;        // np.var, ddof = 0 (:69, :70)
             s_gk[kk * kRowsWG + lane] = make_double2(g, kb);              // the step's record: {G_kj, kb_j} per row
+            if (s == kEarly - 1 && lane == 0) g_ctl_set(&ctl[cHalf], 2 * b + 1);  // the G waves may start on the next band's rows
+            if (s >= kEarly) {
+              gprev[s - kEarly] = g;
+              gamprev[s - kEarly] = gam;
+            }
           }
         }
         // per band: the latched scalars of the obs done so far, L^-1 (LinvA[b][t][s], zero where s < t or s >= 8), flags
@@ -503,33 +523,39 @@ __global__ __launch_bounds__(kGT) void k_pipe_band(const PipeArgs a) {
       for (int jj = 0; jj < 2; ++jj)
 #pragma unroll
         for (int v = 0; v < 4; ++v) acc[I][jj][v] = G_s[(16 * I + 4 * v + lr) * kRowsWG + 16 * (2 * h + jj) + lc];
-    for (int b = 0; b + 1 < nbands; ++b) {  // nothing follows the last band
+    for (int b = 0; b + 1 < nbands; ++b) {  // nothing follows the last band (a band before the last one is always full)
       const int r0 = kBand * b;
-      if (!wait_gt(&ctl[cSReady], r0 + kBand - 1, false)) break;  // (a band before the last one is always full)
-      // From the records {G_kj, kb_j} alone: G_ij -= kb_j G_ki + kb_i (G_kj - kb_j G_kk), two products per K slice of
-      // four steps: (A1 = -G_ki, B1 = kb_j) and (A2 = -kb_i, B2 = t_j).  B operands of this wave's 32 columns:
-      double b1[kBand / 4][2], b2[kBand / 4][2];
-#pragma unroll
-      for (int q = 0; q < kBand / 4; ++q) {
-        const int st = r0 + 4 * q + lr;                       // this lane's K slot: step st
-        const double Gkk = s_gk[st * kRowsWG + st].x;
-#pragma unroll
-        for (int jj = 0; jj < 2; ++jj) {
-          const double2 r = s_gk[st * kRowsWG + 16 * (2 * h + jj) + lc];
-          b1[q][jj] = r.y;
-          b2[q][jj] = __builtin_fma(-r.y, Gkk, r.x);
-        }
-      }
       const int Inext = (r0 + kBand) >> 4;  // tile row of the next band
-      auto update_row = [&](auto Itag) {
+      // From the records {G_kj, kb_j} alone: G_ij -= kb_j G_ki + kb_i (G_kj - kb_j G_kk), two products per K slice of
+      // four steps: (A1 = -G_ki, B1 = kb_j) and (A2 = -kb_i, B2 = t_j).  Steps outside [lo, hi) of the band are masked.
+      double b1[kBand / 4][2], b2[kBand / 4][2];
+      auto load_b = [&](int lo, int hi) {
+#pragma unroll
+        for (int q = 0; q < kBand / 4; ++q) {
+          const int sb = 4 * q + lr;                            // this lane's K slot: step r0 + sb
+          const bool on = sb >= lo && sb < hi;
+          const int st = r0 + (on ? sb : 0);
+          const double Gkk = s_gk[st * kRowsWG + st].x;
+#pragma unroll
+          for (int jj = 0; jj < 2; ++jj) {
+            const double2 r = s_gk[st * kRowsWG + 16 * (2 * h + jj) + lc];
+            b1[q][jj] = on ? r.y : 0.0;
+            b2[q][jj] = on ? __builtin_fma(-r.y, Gkk, r.x) : 0.0;
+          }
+        }
+      };
+      auto update_row = [&](auto Itag, int lo, int hi) {
         constexpr int I = decltype(Itag)::value;
 #pragma unroll
         for (int q = 0; q < kBand / 4; ++q) {
-          const double2 r = s_gk[(r0 + 4 * q + lr) * kRowsWG + 16 * I + lc];  // A[i = lc][s = lr]
+          const int sb = 4 * q + lr;
+          const bool on = sb >= lo && sb < hi;
+          const double2 r = s_gk[(r0 + (on ? sb : 0)) * kRowsWG + 16 * I + lc];  // A[i = lc][s = lr]
+          const double a1 = on ? -r.x : 0.0, a2 = on ? -r.y : 0.0;
 #pragma unroll
           for (int jj = 0; jj < 2; ++jj) {
-            acc[I][jj] = __builtin_amdgcn_mfma_f64_16x16x4f64(-r.x, b1[q][jj], acc[I][jj], 0, 0, 0);
-            acc[I][jj] = __builtin_amdgcn_mfma_f64_16x16x4f64(-r.y, b2[q][jj], acc[I][jj], 0, 0, 0);
+            acc[I][jj] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b1[q][jj], acc[I][jj], 0, 0, 0);
+            acc[I][jj] = __builtin_amdgcn_mfma_f64_16x16x4f64(a2, b2[q][jj], acc[I][jj], 0, 0, 0);
           }
         }
       };
@@ -546,17 +572,32 @@ __global__ __launch_bounds__(kGT) void k_pipe_band(const PipeArgs a) {
           }
         }
       };
-      switch (Inext) {  // the next band's tile row first, handed over at once
-        case 0: update_row(std::integral_constant<int, 0>()); hand_over(std::integral_constant<int, 0>()); break;
-        case 1: update_row(std::integral_constant<int, 1>()); hand_over(std::integral_constant<int, 1>()); break;
-        case 2: update_row(std::integral_constant<int, 2>()); hand_over(std::integral_constant<int, 2>()); break;
-        default: update_row(std::integral_constant<int, 3>()); hand_over(std::integral_constant<int, 3>()); break;
+      // phase 1, as soon as the band's first kEarly steps are published: those steps applied to the tile row of the
+      // NEXT band, whose rows go back to the pivot wave at once (it applies the band's other steps itself)
+      if (!wait_gt(&ctl[cHalf], 2 * b, false)) break;
+      load_b(0, kEarly);
+      switch (Inext) {
+        case 0: update_row(std::integral_constant<int, 0>(), 0, kEarly); hand_over(std::integral_constant<int, 0>()); break;
+        case 1: update_row(std::integral_constant<int, 1>(), 0, kEarly); hand_over(std::integral_constant<int, 1>()); break;
+        case 2: update_row(std::integral_constant<int, 2>(), 0, kEarly); hand_over(std::integral_constant<int, 2>()); break;
+        default: update_row(std::integral_constant<int, 3>(), 0, kEarly); hand_over(std::integral_constant<int, 3>()); break;
       }
       if (lane == 0) g_ctl_set(&ctl[cBandH + h], b + 1);
-      // the tile rows below it (rows of later bands only)
-      if (Inext < 1) update_row(std::integral_constant<int, 1>());
-      if (Inext < 2) update_row(std::integral_constant<int, 2>());
-      if (Inext < 3) update_row(std::integral_constant<int, 3>());
+      // phase 2, after the band: its other steps for that tile row, the whole band for the tile rows below it
+      if (!wait_gt(&ctl[cSReady], r0 + kBand - 1, false)) break;
+      load_b(kEarly, kBand);
+      switch (Inext) {
+        case 0: update_row(std::integral_constant<int, 0>(), kEarly, kBand); break;
+        case 1: update_row(std::integral_constant<int, 1>(), kEarly, kBand); break;
+        case 2: update_row(std::integral_constant<int, 2>(), kEarly, kBand); break;
+        default: update_row(std::integral_constant<int, 3>(), kEarly, kBand); break;
+      }
+      if (Inext < 3) {
+        load_b(0, kBand);
+        if (Inext < 1) update_row(std::integral_constant<int, 1>(), 0, kBand);
+        if (Inext < 2) update_row(std::integral_constant<int, 2>(), 0, kBand);
+        update_row(std::integral_constant<int, 3>(), 0, kBand);
+      }
     }
     __syncthreads();  // B3
     return;
@@ -587,6 +628,9 @@ __global__ __launch_bounds__(kGT) void k_pipe_band(const PipeArgs a) {
   while (k < P && !bailed) {
     if (leads && k == own0) {
       // ---------------- this workgroup's block ----------------
+#ifdef EFA_PIPE_BLOCKTIME
+      if (a.dbg != nullptr && lane == 0) a.dbg[(size_t)(own0 + wave) * 8 + 4] = __builtin_amdgcn_s_memtime();  // per vector wave
+#endif
 #pragma unroll
       for (int c = 0; c < NC; ++c)
         *reinterpret_cast<double2*>(Yt + (size_t)i_loc * SP + 2 * PLg * c + 2 * j) = make_double2(x[2 * c], x[2 * c + 1]);
@@ -596,6 +640,7 @@ __global__ __launch_bounds__(kGT) void k_pipe_band(const PipeArgs a) {
         pm[kRowsWG + i_loc] = xm;
       }
       __syncthreads();  // B1: tile and parked means complete
+      EFA_BLOCKSTAMP(wave == 0 && lane == 0, 5);
       form_gram();
       // For the block the rows change layout: wave w re-reads the 16 rows it has just parked (rows 4 rho + w,
       // rho = 0..15) as NJ accumulator tiles of v_mfma_f64_16x16x4_f64: register v of tile J in lane l is member

@@ -32,4 +32,12 @@ pre = [t[64 * b, 0] - t[64 * b, 3] for b in range(1, nb)]
 print("bits %d gram %d kind %d obs_ms %.3f" % (bits, gram, ctx.get_option("phase_a_kind"), ctx.last_timing()["obs_ms"]))
 print("  pivot loop %6.0f cycles/step | pivot start -> last record forwarded %6.0f /step | last foreign record -> pivot start %6.0f cycles"
       % (np.median(piv) / 64, np.median(blk) / 64, np.median(pre)))
+if gram == 2:
+    for w in range(8):
+        print("    vector wave %d reaches its block %6.0f cycles after the last record is in the ring" % (w, np.median([t[64 * b + w, 4] - t[64 * b, 3] for b in range(1, nb)])))
+    a = [t[64 * b, 4] - t[64 * b, 3] for b in range(1, nb)]
+    b1 = [t[64 * b, 5] - t[64 * b, 4] for b in range(1, nb)]
+    c1 = [t[64 * b, 0] - t[64 * b, 5] for b in range(1, nb)]
+    print("  hand-over split: last record in ring -> followers done %6.0f | park + B1 %6.0f | Gram, tile load, B2, band load %6.0f"
+          % (np.median(a), np.median(b1), np.median(c1)))
 ctx.set_option("pipe_debug", 0); ctx.set_option("path", 0); ctx.set_option("gram", 2)
