@@ -805,6 +805,8 @@ hipError_t band_launch(const PipeArgs& a, hipStream_t s) {
 
 }  // namespace
 
+long band_traj_stride(int M) { return 2 * PLg * ((M + 2 * PLg - 1) / (2 * PLg)) + kTrajScalars; }
+
 bool pipeline_band_supported(int M, long R, int loc_mode) {
   if (loc_mode != 0) return false;  // the rank-one form of the downdate needs kb_j = c G_kj (no taper)
   if (!(M >= 2 && M <= 128 && R > 0 && (R + kRowsWG - 1) / kRowsWG <= kPipeMaxWGs)) return false;
