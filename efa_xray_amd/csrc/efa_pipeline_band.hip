@@ -756,27 +756,49 @@ __global__ __launch_bounds__(kGT) void k_pipe_band(const PipeArgs a) {
       k = own1;
       continue;
     }
-    // ---------------- follower step: consume record k from the ring ----------------
+    // ---------------- follower steps: consume the records that are in the ring ----------------
+    // One poll tells how many records are there (the band leader publishes four at a time); they are then applied
+    // without further polls, the LDS reads of record k+1 issued before the arithmetic of record k (two register
+    // sets, the loop is unrolled by two), and the progress word is written once per batch: a follower is bound by
+    // what one wave can issue, so every instruction per record counts.
     if (!wait_gt(&ctl[cReady], (int)k, true)) {
       bailed = true;
       break;
     }
-    const double* slot = ring + (size_t)(k % kRingG) * TS;
-    double y[2 * NC];
-    lds_read_row<PLg, NC>(slot, j, y);
-    const double2 s01 = *reinterpret_cast<const double2*>(slot + PAD);      // rden, beta
-    const double2 s23 = *reinterpret_cast<const double2*>(slot + PAD + 2);  // innov, active
-    if (lane == 0) g_ctl_set(&ctl[cProg + wave], (int)k);
-    if (__builtin_amdgcn_readfirstlane((int)(s23.y != 0.0)) != 0) {
-      const double dot = group_dot<PLg, NC>(x, y);
-      const double kc = dot * rM1;                        // :95
-      const double km = kc * s01.x;                       // :119
-      xm = xm + km * s23.x;                               // :130
-      const double kb = s01.y * km;                       // :136
+    long avail = g_ctl(&ctl[cReady]);
+    const long lim = (leads && k < own0) ? own0 : P;
+    if (avail > lim) avail = lim;
+    if (avail > k + kRingG / 2) avail = k + kRingG / 2;  // progress is reported at least every half ring (slot recycling)
+    double ya[2 * NC], yb2[2 * NC];
+    double2 a01, a23, b01, b23;
+    auto fetch = [&](long kk, double (&y)[2 * NC], double2& s01, double2& s23) {
+      const double* slot = ring + (size_t)(kk % kRingG) * TS;
+      lds_read_row<PLg, NC>(slot, j, y);
+      s01 = *reinterpret_cast<const double2*>(slot + PAD);      // rden, beta
+      s23 = *reinterpret_cast<const double2*>(slot + PAD + 2);  // innov, active
+    };
+    auto apply = [&](const double (&y)[2 * NC], const double2 s01, const double2 s23) {
+      if (__builtin_amdgcn_readfirstlane((int)(s23.y != 0.0)) != 0) {
+        const double dot = group_dot<PLg, NC>(x, y);
+        const double kc = dot * rM1;                        // :95
+        const double km = kc * s01.x;                       // :119
+        xm = xm + km * s23.x;                               // :130
+        const double kb = s01.y * km;                       // :136
 #pragma unroll
-      for (int c = 0; c < 2 * NC; ++c) x[c] = __builtin_fma(-kb, y[c], x[c]);  // :141
+        for (int c = 0; c < 2 * NC; ++c) x[c] = __builtin_fma(-kb, y[c], x[c]);  // :141
+      }
+    };
+    fetch(k, ya, a01, a23);
+    while (k < avail) {
+      if (k + 1 < avail) fetch(k + 1, yb2, b01, b23);
+      apply(ya, a01, a23);
+      ++k;
+      if (k >= avail) break;
+      if (k + 1 < avail) fetch(k + 1, ya, a01, a23);
+      apply(yb2, b01, b23);
+      ++k;
     }
-    ++k;
+    if (lane == 0) g_ctl_set(&ctl[cProg + wave], (int)(k - 1));
   }
   for (; barriers_left > 0; --barriers_left) __syncthreads();
   if (bailed || g_ctl(&ctl[cBail]) != 0) return;  // nothing written back: the host re-runs Phase A
