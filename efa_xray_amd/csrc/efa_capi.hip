@@ -108,10 +108,8 @@ struct efa_ctx {
   DevBuf Yw, ymw;  // obs block workspace [(P+M)][M], [(P+M)]
   // --- state phase workspaces ---------------------------------------------
   DevBuf W;           // taper table [nb][ncol]
-  DevBuf gc_cnt, gc_off, gc_idx, gc_wts, gc_pairs;  // one-pass GC sweep: CSR active lists
+  DevBuf gc_cnt, gc_ub, gc_order, gc_off, gc_idx, gc_wts, gc_pairs;  // one-pass GC sweep: CSR active lists
   long gc_active_pairs = 0;  // (column, ob) pairs with a non-zero taper in the last one-pass sweep
-  std::vector<int> h_cnt;
-  std::vector<long> h_off;
   DevBuf glat, glon;  // grid lat/lon [ncol]
   DevBuf xm_ws;       // means for efa_state_cycle_dev
   // --- f1: interpolation stencils -------------------------------------------------
@@ -428,38 +426,30 @@ int state_gc_onepass(efa_ctx* c, long rows, const double* xm_in, const double* X
   hipStream_t s = c->stream;
   const long nblk = gc_num_blocks(ncol);
   EFA_TRY(c->gc_cnt.reserve((size_t)nblk * sizeof(int)));
+  EFA_TRY(c->gc_ub.reserve((size_t)nblk * sizeof(int)));
+  EFA_TRY(c->gc_order.reserve((size_t)nblk * sizeof(int)));
   EFA_TRY(c->gc_off.reserve((size_t)(nblk + 1) * sizeof(long)));
   EFA_TRY(c->gc_pairs.reserve(sizeof(unsigned long long)));
   EFA_HIP(hipMemsetAsync(c->gc_pairs.p, 0, sizeof(unsigned long long), s));
-  EFA_HIP(launch_gc_count(ncol, P, c->glat.as<double>(), c->glon.as<double>(), c->ob_lat.as<double>(),
-                          c->ob_lon.as<double>(), c->ob_hw.as<double>(), c->coef.as<double>(), c->gc_cnt.as<int>(),
-                          c->gc_pairs.as<unsigned long long>(), s));
-  c->h_cnt.resize((size_t)nblk);
-  c->h_off.resize((size_t)nblk + 1);
-  unsigned long long h_pairs = 0;
-  EFA_HIP(hipMemcpyAsync(c->h_cnt.data(), c->gc_cnt.p, (size_t)nblk * sizeof(int), hipMemcpyDeviceToHost, s));
-  EFA_HIP(hipMemcpyAsync(&h_pairs, c->gc_pairs.p, sizeof(h_pairs), hipMemcpyDeviceToHost, s));
+  EFA_HIP(launch_gc_bound(ncol, P, c->glat.as<double>(), c->ob_lat.as<double>(), c->ob_hw.as<double>(),
+                          c->coef.as<double>(), c->gc_ub.as<int>(), c->gc_off.as<long>(), s));
+  long cap = 0;  // the only host round trip of the build: 8 bytes, the capacity the lists need
+  EFA_HIP(hipMemcpyAsync(&cap, c->gc_off.as<long>() + nblk, sizeof(long), hipMemcpyDeviceToHost, s));
   EFA_HIP(hipStreamSynchronize(s));
-  c->gc_active_pairs = (long)h_pairs;
-  long nnz = 0;
-  for (long b = 0; b < nblk; ++b) {
-    c->h_off[b] = nnz;
-    nnz += c->h_cnt[b];
-  }
-  c->h_off[nblk] = nnz;
-  EFA_HIP(hipMemcpyAsync(c->gc_off.p, c->h_off.data(), (size_t)(nblk + 1) * sizeof(long), hipMemcpyHostToDevice, s));
-  EFA_TRY(c->gc_idx.reserve((size_t)(nnz ? nnz : 1) * sizeof(int)));
-  EFA_TRY(c->gc_wts.reserve((size_t)(nnz ? nnz : 1) * 16 * sizeof(double)));
-  if (nnz)
-    EFA_HIP(launch_gc_fill(ncol, P, c->glat.as<double>(), c->glon.as<double>(), c->ob_lat.as<double>(),
-                           c->ob_lon.as<double>(), c->ob_hw.as<double>(), c->coef.as<double>(), c->gc_off.as<long>(),
-                           c->gc_idx.as<int>(), c->gc_wts.as<double>(), s));
+  EFA_TRY(c->gc_idx.reserve((size_t)(cap ? cap : 1) * sizeof(int)));
+  EFA_TRY(c->gc_wts.reserve((size_t)(cap ? cap : 1) * 16 * sizeof(double)));
+  EFA_HIP(launch_gc_fill(ncol, P, c->glat.as<double>(), c->glon.as<double>(), c->ob_lat.as<double>(),
+                         c->ob_lon.as<double>(), c->ob_hw.as<double>(), c->coef.as<double>(), c->gc_off.as<long>(),
+                         c->gc_cnt.as<int>(), c->gc_idx.as<int>(), c->gc_wts.as<double>(), c->gc_order.as<int>(),
+                         c->gc_pairs.as<unsigned long long>(), s));
   GcSweepArgs g{};
   g.ncol = ncol;
   g.n_lead = n_lead;
   g.M = M;
   g.nblk = nblk;
   g.off = c->gc_off.as<long>();
+  g.cnt = c->gc_cnt.as<int>();
+  g.order = c->gc_order.as<int>();
   g.idx = c->gc_idx.as<int>();
   g.wts = c->gc_wts.as<double>();
   g.coef = c->coef.as<double>();
@@ -471,7 +461,10 @@ int state_gc_onepass(efa_ctx* c, long rows, const double* xm_in, const double* X
   g.xout = xm_out;
   g.fused_members = fused_members;
   EFA_HIP(launch_sweep_gc(g, s));
-  EFA_HIP(hipStreamSynchronize(s));  // h_off is reused by the next call
+  unsigned long long h_pairs = 0;
+  EFA_HIP(hipMemcpyAsync(&h_pairs, c->gc_pairs.p, sizeof(h_pairs), hipMemcpyDeviceToHost, s));
+  EFA_HIP(hipStreamSynchronize(s));
+  c->gc_active_pairs = (long)h_pairs;
   c->state_launches++;
   (void)rows;
   return EFA_OK;
@@ -632,7 +625,7 @@ int efa_ctx_destroy(efa_ctx* c) {
   if (c->stream) (void)hipStreamSynchronize(c->stream);
   DevBuf* bufs[] = {&c->Ye_rec, &c->coef, &c->ob_val, &c->ob_err, &c->ob_asm, &c->ob_lat, &c->ob_lon, &c->ob_hw,
                     &c->d_prior_mean, &c->d_prior_var, &c->d_post_mean, &c->d_post_var, &c->d_assimilated,
-                    &c->Yw, &c->ymw, &c->traj, &c->tw_mat, &c->status, &c->dbg, &c->W, &c->gc_cnt, &c->gc_off, &c->gc_idx, &c->gc_wts, &c->gc_pairs, &c->glat, &c->glon, &c->xm_ws, &c->fs_idx, &c->fs_wts, &c->f_glat, &c->f_glon, &c->f_sl, &c->f_cl, &c->f_valids, &c->f_var, &c->f_time, &c->f_lat, &c->f_lon, &c->f_near, &c->f_idx, &c->f_wts, &c->f_status, &c->h_xm, &c->h_Xp, &c->h_ym, &c->h_Yp};
+                    &c->Yw, &c->ymw, &c->traj, &c->tw_mat, &c->status, &c->dbg, &c->W, &c->gc_cnt, &c->gc_ub, &c->gc_order, &c->gc_off, &c->gc_idx, &c->gc_wts, &c->gc_pairs, &c->glat, &c->glon, &c->xm_ws, &c->fs_idx, &c->fs_wts, &c->f_glat, &c->f_glon, &c->f_sl, &c->f_cl, &c->f_valids, &c->f_var, &c->f_time, &c->f_lat, &c->f_lon, &c->f_near, &c->f_idx, &c->f_wts, &c->f_status, &c->h_xm, &c->h_Xp, &c->h_ym, &c->h_Yp};
   for (DevBuf* b : bufs) b->release();
   for (int i = 0; i < 4; ++i)
     if (c->ev[i]) (void)hipEventDestroy(c->ev[i]);

@@ -6,12 +6,12 @@
 // exactly 0 beyond 2 x halfwidth, where the update leaves the row bit-unchanged.  So
 //   1. k_gc_build evaluates haversine + Gaspari-Cohn ONCE per (column, observation) -- not per
 //      state row -- and keeps, per block of 16 columns, the ascending list of observations with
-//      any non-zero weight together with the 16 weights (CSR: off / idx / wts);
-//   2. k_sweep_gc gives each workgroup one column block; its 4 waves walk the n_lead
-//      variable x time slabs of those 16 columns (quad per row: 16 rows = 10 KB contiguous),
-//      and for each slab loop over the block's active list only.  ye rows and coefficients of
-//      the active observations come from L2 (the recorded trajectory is a few MB), software
-//      prefetched one entry ahead; the taper block is re-read by the 148 slabs from L1/L2.
+//      any non-zero weight together with the 16 weights (off / cnt / idx / wts).  One pass over the
+//      trigonometry: a latitude-only upper bound per block (k_gc_bound) and a device prefix sum
+//      (k_gc_scan) place the lists; k_gc_order sorts the blocks longest list first;
+//   2. k_sweep_gc gives each workgroup one column block; its 4 waves (4 columns each) walk the n_lead
+//      variable x time slabs of those columns (quad per row), and for each group of slabs loop over the
+//      block's active list only, staged through LDS 32 observations at a time.
 // Work drops from P passes' worth to (active fraction) x P; HBM traffic to one read + one write.
 #include "efa_device.h"
 #include "efa_internal.h"
@@ -26,9 +26,116 @@ constexpr int kBlkCols = 16;  // columns per block == rows per wave in the quad 
 // observations per step in ascending order.  Everything the list needs is wave-local (ballot +
 // a running count in a scalar register), so the loop has no workgroup barrier; the exact
 // latitude rejection keeps the trigonometry to the few observations near the block.
-// FILL = false: count only.
+//
+// The lists are built in ONE pass over the trigonometry: k_gc_bound counts, per block, the observations
+// that survive the latitude test alone (an upper bound of the list length, no trigonometry), k_gc_scan
+// turns the bounds into offsets on the device, and k_gc_build writes each block's entries at its offset
+// and records the true length in cnt[b] (the space between a block's end and the next offset stays unused).
 constexpr int kBuildWaves = 4;  // column blocks per workgroup
-template <bool FILL>
+
+// the block's latitude range, the same in every lane
+__device__ __forceinline__ void block_lat_range(bool col_ok, double la, double& la_lo, double& la_hi) {
+  la_lo = col_ok ? la : 1e300;
+  la_hi = col_ok ? la : -1e300;
+#pragma unroll
+  for (int m = 1; m < 64; m <<= 1) {
+    la_lo = fmin(la_lo, __shfl_xor(la_lo, m, 64));
+    la_hi = fmax(la_hi, __shfl_xor(la_hi, m, 64));
+  }
+}
+
+// 64 observations at once, lane <-> observation: the great-circle distance to ANY column of the
+// block is at least R * (latitude gap to the block's range); beyond 2 x halfwidth the
+// Gaspari-Cohn weight is exactly 0, so most observations never reach the trigonometry
+__device__ __forceinline__ unsigned long long lat_candidates(long k, long P, double la_lo, double la_hi,
+                                                             const double* __restrict__ ob_lat,
+                                                             const double* __restrict__ ob_hw,
+                                                             const double* __restrict__ coef) {
+  bool cnd = false;
+  if (k < P && coef[k * kCoefStride + 3] != 0.0) {
+    const double hw = ob_hw[k], olat = ob_lat[k];
+    const double gap = fmax(0.0, fmax(olat - la_hi, la_lo - olat));
+    cnd = (kEarthRadiusKm * radians(gap) <= 2.0 * fabs(hw) * (1.0 + 1e-9)) || !(hw == hw);
+  }
+  return __ballot(cnd);
+}
+
+__global__ __launch_bounds__(64 * kBuildWaves) void k_gc_bound(long ncol, long nblk, long P,
+                                                               const double* __restrict__ glat,
+                                                               const double* __restrict__ ob_lat,
+                                                               const double* __restrict__ ob_hw,
+                                                               const double* __restrict__ coef, int* __restrict__ ub) {
+  const int lane = threadIdx.x & 63;
+  const long b = (long)blockIdx.x * kBuildWaves + (threadIdx.x >> 6);
+  if (b >= nblk) return;
+  const long col = b * kBlkCols + (lane & 15);
+  const bool col_ok = col < ncol;
+  double la_lo, la_hi;
+  block_lat_range(col_ok, col_ok ? glat[col] : 0.0, la_lo, la_hi);
+  int n = 0;
+  for (long k0 = 0; k0 < P; k0 += 64) n += __builtin_popcountll(lat_candidates(k0 + lane, P, la_lo, la_hi, ob_lat, ob_hw, coef));
+  if (lane == 0) ub[b] = n;
+}
+
+// off[b] = sum of ub[0..b), off[nblk] = total; one workgroup (nblk is ncol / 16: tens of thousands)
+constexpr int kScanThreads = 1024;
+__global__ __launch_bounds__(kScanThreads) void k_gc_scan(long nblk, const int* __restrict__ ub, long* __restrict__ off) {
+  __shared__ long part[kScanThreads];
+  const int t = threadIdx.x;
+  const long per = (nblk + kScanThreads - 1) / kScanThreads;
+  const long lo = (long)t * per, hi = (lo + per < nblk) ? lo + per : nblk;
+  long sum = 0;
+  for (long b = lo; b < hi; ++b) sum += ub[b];
+  part[t] = sum;
+  __syncthreads();
+  for (int d = 1; d < kScanThreads; d <<= 1) {  // inclusive Hillis-Steele over the per-thread sums
+    const long v = (t >= d) ? part[t - d] : 0;
+    __syncthreads();
+    part[t] += v;
+    __syncthreads();
+  }
+  long run = part[t] - sum;
+  for (long b = lo; b < hi; ++b) {
+    off[b] = run;
+    run += ub[b];
+  }
+  if (t == kScanThreads - 1) off[nblk] = part[t];
+}
+
+// order[i] = the block with the i-th longest list (counting sort on cnt >> shift, one workgroup): the sweep
+// hands out blocks longest first, so the last workgroups to start are the cheapest ones.  On a regular
+// lat/lon grid the lists near the poles are several times longer than near the equator, and in blockIdx
+// order the polar rows are both the first and the LAST blocks: the tail of the launch then runs on a few CUs.
+__global__ __launch_bounds__(kScanThreads) void k_gc_order(long nblk, const int* __restrict__ cnt, int shift,
+                                                          int* __restrict__ order) {
+  __shared__ int hist[kScanThreads];
+  const int t = threadIdx.x;
+  hist[t] = 0;
+  __syncthreads();
+  for (long b = t; b < nblk; b += kScanThreads) {
+    int key = cnt[b] >> shift;
+    key = kScanThreads - 1 - (key < kScanThreads ? key : kScanThreads - 1);
+    atomicAdd(&hist[key], 1);
+  }
+  __syncthreads();
+  const int mine = hist[t];
+  for (int d = 1; d < kScanThreads; d <<= 1) {
+    const int v = (t >= d) ? hist[t - d] : 0;
+    __syncthreads();
+    hist[t] += v;
+    __syncthreads();
+  }
+  const int excl = hist[t] - mine;
+  __syncthreads();
+  hist[t] = excl;
+  __syncthreads();
+  for (long b = t; b < nblk; b += kScanThreads) {
+    int key = cnt[b] >> shift;
+    key = kScanThreads - 1 - (key < kScanThreads ? key : kScanThreads - 1);
+    order[atomicAdd(&hist[key], 1)] = (int)b;
+  }
+}
+
 __global__ __launch_bounds__(64 * kBuildWaves) void k_gc_build(long ncol, long nblk, long P,
                                                                const double* __restrict__ glat,
                                                                const double* __restrict__ glon,
@@ -46,30 +153,13 @@ __global__ __launch_bounds__(64 * kBuildWaves) void k_gc_build(long ncol, long n
   const long col = b * kBlkCols + c;
   const bool col_ok = col < ncol;
   const double la = col_ok ? glat[col] : 0.0, lo = col_ok ? glon[col] : 0.0;
-  // latitude range of the block's columns (the same in every lane)
-  double la_lo = col_ok ? la : 1e300, la_hi = col_ok ? la : -1e300;
-#pragma unroll
-  for (int m = 1; m < 64; m <<= 1) {
-    la_lo = fmin(la_lo, __shfl_xor(la_lo, m, 64));
-    la_hi = fmax(la_hi, __shfl_xor(la_hi, m, 64));
-  }
-  long running = FILL ? off[b] : 0;
+  double la_lo, la_hi;
+  block_lat_range(col_ok, la, la_lo, la_hi);
+  const long first = off[b];
+  long running = first;
   long pairs = 0;  // (column, observation) pairs with a non-zero taper: SURVEY.md 8d's bytes_touched
   for (long k0 = 0; k0 < P; k0 += 64) {
-    // 64 observations at once, lane <-> observation: the great-circle distance to ANY column of the
-    // block is at least R * (latitude gap to the block's range); beyond 2 x halfwidth the
-    // Gaspari-Cohn weight is exactly 0, so most observations never reach the trigonometry
-    unsigned long long cand;
-    {
-      const long k = k0 + lane;
-      bool cnd = false;
-      if (k < P && coef[k * kCoefStride + 3] != 0.0) {
-        const double hw = ob_hw[k], olat = ob_lat[k];
-        const double gap = fmax(0.0, fmax(olat - la_hi, la_lo - olat));
-        cnd = (kEarthRadiusKm * radians(gap) <= 2.0 * fabs(hw) * (1.0 + 1e-9)) || !(hw == hw);
-      }
-      cand = __ballot(cnd);
-    }
+    unsigned long long cand = lat_candidates(k0 + lane, P, la_lo, la_hi, ob_lat, ob_hw, coef);
     while (cand != 0ull) {  // four candidates per step, ascending
       int kb[4];
 #pragma unroll
@@ -95,7 +185,7 @@ __global__ __launch_bounds__(64 * kBuildWaves) void k_gc_build(long ncol, long n
         before += (i < o) ? f : 0;
         total += f;
       }
-      if (FILL && ((bal >> (16 * o)) & 0xFFFFull) != 0ull) {
+      if (((bal >> (16 * o)) & 0xFFFFull) != 0ull) {
         const long e = running + before;
         if (c == 0) idx[e] = (int)k;
         wts[e * kBlkCols + c] = w;
@@ -103,21 +193,48 @@ __global__ __launch_bounds__(64 * kBuildWaves) void k_gc_build(long ncol, long n
       running += total;
     }
   }
-  if (!FILL && lane == 0) {
-    cnt[b] = (int)running;
+  if (lane == 0) {
+    cnt[b] = (int)(running - first);
     if (npairs) atomicAdd(npairs, (unsigned long long)pairs);
   }
 }
 
 constexpr int kChunk = 32;  // active observations staged in LDS at a time
 
-// Workgroup = one column block, 4 waves = 4 variable x time slabs processed in lock step: the
-// block's active observations are staged chunk by chunk into LDS ONCE per group of 4 slabs (ye
-// rows, tapers, coefficients), so the per-lane traffic of the inner loop is LDS only.  Fetching ye
-// per lane straight from L2 made the kernel vector-memory-issue bound (10 x 1 KB requests per
+// Workgroup = one column block.  Wave w owns columns 4w .. 4w+3 of the block; its 16 quads are 4 columns x 4
+// variable x time slabs, RPL rows (slabs) per quad, so the four waves walk the same 4 RPL slabs of different
+// columns in lock step.  The block's active observations are staged chunk by chunk into LDS ONCE per group
+// of slabs (ye rows, tapers, coefficients), so the per-lane traffic of the inner loop is LDS only; a wave
+// skips an observation whose taper is zero on all of ITS four columns (the list is per 16 columns, and a
+// block spans up to 8 degrees of longitude: a sixth of the listed (column, ob) pairs have zero weight).
+// Fetching ye per lane straight from L2 made the kernel vector-memory-issue bound (10 x 1 KB requests per
 // wave and observation through one 64 B/clk path per CU).
+// The kernel is bound by fp64 VALU issue (profiles/r02_cfg3_summary.txt: 57 % of its VALU instructions are the
+// 4 M FMAs per (row, ob) the arithmetic needs, VALU busy 3/4 of the time); three waves per SIMD (<= 168 VGPRs).
+#ifndef EFA_GC_MINWAVES
+#define EFA_GC_MINWAVES 3
+#endif
+#ifndef EFA_GC_RPL
+#define EFA_GC_RPL 2
+#endif
+#ifndef EFA_GC_COLSPLIT
+#define EFA_GC_COLSPLIT 1
+#endif
+// dot(x, ye) over the lane's slots with two FMA chains (the other row of the quad and the other waves
+// of the SIMD fill the issue slots), then the quad total
+template <int NC>
+__device__ __forceinline__ double gc_dot(const double (&x)[2 * NC], const double (&y)[2 * NC]) {
+  double s0 = x[0] * y[0], s1 = x[1] * y[1];
+#pragma unroll
+  for (int c = 1; c < NC; ++c) {
+    s0 = __builtin_fma(x[2 * c], y[2 * c], s0);
+    s1 = __builtin_fma(x[2 * c + 1], y[2 * c + 1], s1);
+  }
+  return group_sum<4>(s0 + s1);
+}
+
 template <int NC, bool VEC, bool FUSED, int RPL>
-__global__ __launch_bounds__(256) void k_sweep_gc(const GcSweepArgs a) {
+__global__ __launch_bounds__(256, EFA_GC_MINWAVES) void k_sweep_gc(const GcSweepArgs a) {
   constexpr int L = 4;
   constexpr int S = 2 * L * NC;  // padded ye row (doubles)
   __shared__ __align__(16) double ye_s[kChunk * S];
@@ -126,16 +243,19 @@ __global__ __launch_bounds__(256) void k_sweep_gc(const GcSweepArgs a) {
   const int tid = threadIdx.x;
   const int wave = tid >> 6, lane = tid & 63;
   const int j = lane & 3, r = lane >> 2;
-  const long b = blockIdx.x;
-  const long col = b * kBlkCols + r;
+  const long b = a.order[blockIdx.x];
+  // quad r of wave w: column cq of the block, slab slot sq of the group of slabs
+  const int cq = EFA_GC_COLSPLIT ? 4 * wave + (r & 3) : r;
+  const int sq = EFA_GC_COLSPLIT ? (r >> 2) : wave;
+  const long col = b * kBlkCols + cq;
   const bool col_ok = col < a.ncol;
   const int M = a.M;
   const double rM1 = 1.0 / (double)(M - 1);
-  const long e0 = a.off[b], e1 = a.off[b + 1];
+  const long e0 = a.off[b], e1 = e0 + a.cnt[b];
 
   // A quad holds RPL rows of the SAME column (slabs lead, lead + 4, ...): they share the taper and
-  // every ye row read from LDS, which is what bounds this kernel (the quad layout delivers each ye
-  // row once per quad), and a staged chunk serves 4 RPL slabs instead of 4.
+  // every ye row read from LDS (the quad layout delivers each ye row once per quad), and a staged
+  // chunk serves 4 RPL slabs instead of 4.
   for (long lead0 = 0; lead0 < a.n_lead; lead0 += 4 * RPL) {
     double x[RPL][2 * NC];
     double xm[RPL];
@@ -144,7 +264,7 @@ __global__ __launch_bounds__(256) void k_sweep_gc(const GcSweepArgs a) {
     bool any_live = false;
 #pragma unroll
     for (int q = 0; q < RPL; ++q) {
-      const long lead = lead0 + wave + 4 * q;
+      const long lead = lead0 + sq + 4 * q;
       live[q] = col_ok && lead < a.n_lead;
       any_live = any_live || live[q];
       row[q] = lead * a.ncol + col;
@@ -190,16 +310,16 @@ __global__ __launch_bounds__(256) void k_sweep_gc(const GcSweepArgs a) {
       __syncthreads();
       // ---- apply the chunk to this wave's 16 RPL rows
       for (int ee = 0; ee < ne; ++ee) {
-        const double w = any_live ? wt_s[ee * kBlkCols + r] : 0.0;
+        const double w = any_live ? wt_s[ee * kBlkCols + cq] : 0.0;
         if (__ballot(w != 0.0) == 0ull) continue;  // none of this wave's rows (dead slabs / zero taper)
         double y[2 * NC];
         lds_read_row<L, NC>(ye_s + ee * S, j, y);
         const double* ck = cf_s + ee * 4;
 #pragma unroll
         for (int q = 0; q < RPL; ++q) {
-          const double dot = group_dot<L, NC>(x[q], y);
+          const double dot = gc_dot<NC>(x[q], y);
           double kc = dot * rM1;            // :95
-          kc = (live[q] ? w : 0.0) * kc;    // :115
+          kc = w * kc;                      // :115 (a dead row holds zeros: its dot, and so its update, is exactly 0)
           const double km = kc * ck[1];     // :119
           xm[q] = xm[q] + km * ck[0];       // :130
           const double kb = ck[2] * km;     // :136
@@ -228,7 +348,7 @@ template <int NC>
 hipError_t gc_launch(const GcSweepArgs& a, hipStream_t s) {
   const bool vec = (a.M % 2 == 0) && (a.ye_stride % 2 == 0) && aligned16(a.Xin) && aligned16(a.Xout) && aligned16(a.Ye);
   const dim3 grid((unsigned)a.nblk), block(256);
-  constexpr int RPL = (NC <= 13) ? 2 : 1;  // two rows per quad while they fit the register file at 2+ waves per SIMD
+  constexpr int RPL = (NC <= 13) ? EFA_GC_RPL : 1;  // two rows per quad while they fit the register file
   if (a.fused_members) {
     if (vec) hipLaunchKernelGGL((k_sweep_gc<NC, true, true, RPL>), grid, block, 0, s, a);
     else hipLaunchKernelGGL((k_sweep_gc<NC, false, true, RPL>), grid, block, 0, s, a);
@@ -243,23 +363,26 @@ hipError_t gc_launch(const GcSweepArgs& a, hipStream_t s) {
 
 long gc_num_blocks(long ncol) { return (ncol + kBlkCols - 1) / kBlkCols; }
 
-hipError_t launch_gc_count(long ncol, long P, const double* glat, const double* glon, const double* ob_lat,
-                           const double* ob_lon, const double* ob_hw, const double* coef, int* cnt, unsigned long long* npairs,
-                           hipStream_t s) {
+hipError_t launch_gc_bound(long ncol, long P, const double* glat, const double* ob_lat, const double* ob_hw,
+                           const double* coef, int* ub, long* off, hipStream_t s) {
   const long nblk = gc_num_blocks(ncol);
   if (nblk <= 0) return hipSuccess;
-  hipLaunchKernelGGL((k_gc_build<false>), dim3((unsigned)((nblk + kBuildWaves - 1) / kBuildWaves)), dim3(64 * kBuildWaves), 0,
-                     s, ncol, nblk, P, glat, glon, ob_lat, ob_lon, ob_hw, coef, cnt, nullptr, nullptr, nullptr, npairs);
+  hipLaunchKernelGGL(k_gc_bound, dim3((unsigned)((nblk + kBuildWaves - 1) / kBuildWaves)), dim3(64 * kBuildWaves), 0, s, ncol,
+                     nblk, P, glat, ob_lat, ob_hw, coef, ub);
+  hipLaunchKernelGGL(k_gc_scan, dim3(1), dim3(kScanThreads), 0, s, nblk, ub, off);
   return hipGetLastError();
 }
 
 hipError_t launch_gc_fill(long ncol, long P, const double* glat, const double* glon, const double* ob_lat,
-                          const double* ob_lon, const double* ob_hw, const double* coef, const long* off, int* idx,
-                          double* wts, hipStream_t s) {
+                          const double* ob_lon, const double* ob_hw, const double* coef, const long* off, int* cnt,
+                          int* idx, double* wts, int* order, unsigned long long* npairs, hipStream_t s) {
   const long nblk = gc_num_blocks(ncol);
   if (nblk <= 0) return hipSuccess;
-  hipLaunchKernelGGL((k_gc_build<true>), dim3((unsigned)((nblk + kBuildWaves - 1) / kBuildWaves)), dim3(64 * kBuildWaves), 0,
-                     s, ncol, nblk, P, glat, glon, ob_lat, ob_lon, ob_hw, coef, nullptr, off, idx, wts, nullptr);
+  hipLaunchKernelGGL(k_gc_build, dim3((unsigned)((nblk + kBuildWaves - 1) / kBuildWaves)), dim3(64 * kBuildWaves), 0, s,
+                     ncol, nblk, P, glat, glon, ob_lat, ob_lon, ob_hw, coef, cnt, off, idx, wts, npairs);
+  int shift = 0;
+  while ((P >> shift) >= kScanThreads) ++shift;
+  hipLaunchKernelGGL(k_gc_order, dim3(1), dim3(kScanThreads), 0, s, nblk, cnt, shift, order);
   return hipGetLastError();
 }
 

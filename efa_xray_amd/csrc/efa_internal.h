@@ -124,7 +124,9 @@ struct GcSweepArgs {
   long ncol, n_lead;
   int M;
   long nblk;            // column blocks of 16
-  const long* off;      // [nblk+1] CSR offsets into idx / wts
+  const long* off;      // [nblk+1] offsets into idx / wts (a block's entries start at off[b])
+  const int* cnt;       // [nblk] entries of block b
+  const int* order;     // [nblk] blocks by descending list length: workgroup i takes block order[i]
   const int* idx;       // [nnz] observation index, ascending within a block
   const double* wts;    // [nnz][16] taper of the block's 16 columns
   const double* coef;   // [P][kCoefStride]
@@ -137,12 +139,12 @@ struct GcSweepArgs {
   int fused_members;
 };
 long gc_num_blocks(long ncol);
-hipError_t launch_gc_count(long ncol, long P, const double* glat, const double* glon, const double* ob_lat,
-                           const double* ob_lon, const double* ob_hw, const double* coef, int* cnt, unsigned long long* npairs,
-                           hipStream_t s);
+// list build in one pass: upper bounds + device prefix sum (off[nblk] = capacity needed), then the entries
+hipError_t launch_gc_bound(long ncol, long P, const double* glat, const double* ob_lat, const double* ob_hw,
+                           const double* coef, int* ub, long* off, hipStream_t s);
 hipError_t launch_gc_fill(long ncol, long P, const double* glat, const double* glon, const double* ob_lat,
-                          const double* ob_lon, const double* ob_hw, const double* coef, const long* off, int* idx,
-                          double* wts, hipStream_t s);
+                          const double* ob_lon, const double* ob_hw, const double* coef, const long* off, int* cnt,
+                          int* idx, double* wts, int* order, unsigned long long* npairs, hipStream_t s);
 hipError_t launch_sweep_gc(const GcSweepArgs& a, hipStream_t s);
 
 struct TransformArgs {
