@@ -575,7 +575,7 @@ def test_errors_are_loud():
         EnSRF(st, [ob], verbose=False, loc='GC').update()   # localize_radius is None
 
 
-@pytest.mark.parametrize("N,M,P", [(1, 4, 1), (130, 8, 70), (257, 128, 129), (1000, 100, 300), (4096, 128, 512)])
+@pytest.mark.parametrize("N,M,P", [(1, 4, 1), (130, 8, 70), (257, 128, 129), (1000, 100, 300), (4096, 128, 512), (300, 36, 1000), (515, 256, 130)])
 def test_dense_contraction_f32_vs_float64(N, M, P):
     """configs[4] path: fp32 MFMA contraction against a float64 evaluation, rtol 1e-4."""
     ctx = _ctx()
@@ -595,9 +595,16 @@ def test_dense_contraction_f32_vs_float64(N, M, P):
     ref = X.astype(np.float64) @ Ye.astype(np.float64).T
     scale = np.abs(X.astype(np.float64)) @ np.abs(Ye.astype(np.float64)).T   # sum |a b|
     assert np.all(np.abs(C - ref) <= 1e-4 * np.abs(ref) + 2e-6 * scale)
-    # exact f32 FMA chain in k order (the MFMA's documented numerics) for one row
+    # exact f32 FMA chain (the MFMA's documented numerics) for one row, in the kernel's documented member
+    # order: M <= 128 interleaves the two halves (s, KH + s with KH = 8 ceil(M / 16)), larger M runs in k order
+    if M <= 128:
+        KH = 8 * ((M + 15) // 16)
+        order = [k for s_ in range(KH) for k in (s_, KH + s_) if k < M]
+    else:
+        order = list(range(M))
+    assert sorted(order) == list(range(M))
     chain = np.zeros(P, dtype=np.float32)
-    for m in range(M):
+    for m in order:
         chain = (chain.astype(np.float64) + X[0, m].astype(np.float64) * Ye[:, m].astype(np.float64)).astype(np.float32)
     assert np.allclose(C[0], chain, rtol=2e-6, atol=1e-6)
 
