@@ -210,7 +210,8 @@ constexpr int kChunk = 32;  // active observations staged in LDS at a time
 // Fetching ye per lane straight from L2 made the kernel vector-memory-issue bound (10 x 1 KB requests per
 // wave and observation through one 64 B/clk path per CU).
 // The kernel is bound by fp64 VALU issue (profiles/r02_cfg3_summary.txt: 57 % of its VALU instructions are the
-// 4 M FMAs per (row, ob) the arithmetic needs, VALU busy 3/4 of the time); three waves per SIMD (<= 168 VGPRs).
+// 4 M FMAs per (row, ob) the arithmetic needs, VALU busy 3/4 of the time); three waves per SIMD (<= 168 VGPRs)
+// while two rows of up to 80 members fit that budget without spilling, two waves above (M <= 128 at one row per quad).
 #ifndef EFA_GC_MINWAVES
 #define EFA_GC_MINWAVES 3
 #endif
@@ -234,7 +235,7 @@ __device__ __forceinline__ double gc_dot(const double (&x)[2 * NC], const double
 }
 
 template <int NC, bool VEC, bool FUSED, int RPL>
-__global__ __launch_bounds__(256, EFA_GC_MINWAVES) void k_sweep_gc(const GcSweepArgs a) {
+__global__ __launch_bounds__(256, (NC * (RPL + 1) <= 30) ? EFA_GC_MINWAVES : (NC * (RPL + 1) <= 48) ? 2 : 1) void k_sweep_gc(const GcSweepArgs a) {
   constexpr int L = 4;
   constexpr int S = 2 * L * NC;  // padded ye row (doubles)
   __shared__ __align__(16) double ye_s[kChunk * S];
