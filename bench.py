@@ -158,10 +158,19 @@ def main():
     from efa_xray_amd import _lib
     from efa_xray_amd.distributed import ShardedEnSRF, HipEngine
 
+    # EFA_BENCH_REHEARSE=1: every rank on cuda:0 with the gloo backend -- a rehearsal of the N > 1 code path
+    # (sharding, the HX all-reduce, barriers, max-over-ranks) on a one-GPU box; its timings mean nothing and the
+    # driver never sets it.  Normal runs: one rank per GPU over RCCL ("nccl").
+    rehearse = os.environ.get("EFA_BENCH_REHEARSE", "0") == "1"
+    if rehearse:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if rehearse:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
     wl = dict(WORKLOADS[args.workload])
     if args.rows:
@@ -296,7 +305,7 @@ def main():
                       % (rows_g if strong else rows, M, P),
             "value": value, "unit": "obs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None,
-            "dtype": "f64", "data": "synthetic",
+            "dtype": "f64", "data": "synthetic" if not rehearse else "synthetic; REHEARSAL (all ranks on one GPU, gloo): timings are not a measurement",
             "config": {"workload": wl["desc"], "rows_per_gpu": rows, "rows_global": rows_g, "members": M, "obs": P,
                        "loc": loc or "none", "path": path_name, "obs_batch": ctx.get_option("obs_batch"),
                        "phase_a": {1: "pipeline", 2: "per-batch", 3: "pipeline-gram", 4: "pipeline-band"}.get(kind, "?"),
