@@ -35,6 +35,40 @@ def test_library_builds_loads_and_exports_every_declared_symbol():
     assert exported == set(declared)
 
 
+def test_baseline_kernels_fit_their_register_budget():
+    """The kernels BASELINE.json's configs run must not spill vector registers (a launch bound that asked for
+    more waves than two rows of 100 members allow once made configs[3] six times slower without failing any
+    parity test), and the persistent Phase-A kernels must fit one workgroup per CU."""
+    from efa_xray_amd import _lib
+    from _codeobj import kernel_table
+    tab = kernel_table(_lib.LIB_PATH)
+    assert len(tab) > 100
+
+    def find(*parts):
+        hits = [k for n, k in tab.items() if all(p in n for p in parts)]
+        assert len(hits) == 1, (parts, [h[".name"] for h in hits])
+        return hits[0]
+
+    no_spill = [
+        ("k_transformILi13ELb1ELb1ELb1E",),          # headline, configs[1] (M = 100, 50 -> NU 13, 7: checked below)
+        ("k_transformILi7ELb1ELb1ELb1E",),
+        ("k_sweep_gcILi10ELb1ELb1ELi2E",),           # configs[2]: 80 members
+        ("k_sweep_gcILi13ELb1ELb1ELi2E",),           # configs[3]: 100 members
+        ("k_pipe_gramILi10E",), ("k_pipe_gramILi13E",),
+        ("k_contract_f32_raILi64E",),                # configs[4]
+        ("7k_sweepILi4ELi13ELb1E",),                 # the unlocalised batch sweep at M = 100
+    ]
+    for parts in no_spill:
+        k = find(*parts)
+        assert k.get(".vgpr_spill_count", 0) == 0, (k[".name"], k[".vgpr_count"], k[".vgpr_spill_count"])
+    band = find("k_pipe_bandILi13E")                 # headline Phase A: 8 waves of up to 256 registers
+    assert band.get(".vgpr_spill_count", 0) <= 2 and band[".vgpr_count"] <= 256
+    # occupancy the kernels are written for (512 VGPRs per SIMD lane on gfx950)
+    assert find("k_sweep_gcILi10ELb1ELb1ELi2E")[".vgpr_count"] <= 168     # three waves per SIMD
+    assert find("k_sweep_gcILi13ELb1ELb1ELi2E")[".vgpr_count"] <= 256     # two
+    assert find("k_contract_f32_raILi64E")[".vgpr_count"] <= 256
+
+
 def test_no_cpu_fallback_without_gpu():
     """Without a usable device the product fails loudly instead of computing on the CPU."""
     from efa_xray_amd import _lib, EnSRF, EnsembleState, Observation
