@@ -44,8 +44,16 @@ int fail(int code, const char* fmt, ...) {
 struct DevBuf {
   void* p = nullptr;
   size_t cap = 0;
+  bool view = false;  // p points into another DevBuf (carve): never freed here
+  void carve(void* base, size_t bytes) {
+    if (p && !view) (void)hipFree(p);
+    p = base;
+    cap = bytes;
+    view = true;
+  }
   int reserve(size_t bytes) {
     if (bytes <= cap) return EFA_OK;
+    if (view) return fail(EFA_ERR_INVALID, "internal: reserve() on a carved buffer");
     if (p) {
       hipError_t e = hipFree(p);
       p = nullptr;
@@ -62,12 +70,39 @@ struct DevBuf {
     return EFA_OK;
   }
   void release() {
-    if (p) (void)hipFree(p);
+    if (p && !view) (void)hipFree(p);
     p = nullptr;
     cap = 0;
+    view = false;
   }
   template <typename T>
   T* as() const { return reinterpret_cast<T*>(p); }
+};
+
+// grow-only pinned host staging: one asynchronous copy each way instead of one (synchronous, staged by the
+// runtime) copy per pageable caller array
+struct PinBuf {
+  void* p = nullptr;
+  size_t cap = 0;
+  int reserve(size_t bytes) {
+    if (bytes <= cap) return EFA_OK;
+    if (p) (void)hipHostFree(p);
+    p = nullptr;
+    cap = 0;
+    const size_t want = bytes + (bytes >> 2) + 256;
+    hipError_t e = hipHostMalloc(&p, want, hipHostMallocDefault);
+    if (e != hipSuccess) {
+      p = nullptr;
+      return fail(EFA_ERR_HIP, "hipHostMalloc(%zu) failed: %s", want, hipGetErrorString(e));
+    }
+    cap = want;
+    return EFA_OK;
+  }
+  void release() {
+    if (p) (void)hipHostFree(p);
+    p = nullptr;
+    cap = 0;
+  }
 };
 
 }  // namespace
@@ -103,6 +138,8 @@ struct efa_ctx {
   const double* ye_ptr = nullptr;  // where Phase B reads the recorded ye rows
   long ye_stride = 0;
   int phase_a_kind = 0;          // 1 pipeline, 2 per-batch kernels
+  DevBuf ob_pack, out_pack;  // the per-ob inputs / diagnostics below are carved out of these two allocations
+  PinBuf pin_in, pin_out;    // their pinned host images: one H2D and one D2H per call
   DevBuf ob_val, ob_err, ob_asm, ob_lat, ob_lon, ob_hw;  // device copies [P]
   DevBuf d_prior_mean, d_prior_var, d_post_mean, d_post_var, d_assimilated;
   DevBuf Yw, ymw;  // obs block workspace [(P+M)][M], [(P+M)]
@@ -123,8 +160,6 @@ struct efa_ctx {
   double state_ms = 0.0, obs_ms = 0.0;
   long state_launches = 0;
   int path_taken = 0;
-  std::vector<double> h_tmp;
-  std::vector<uint8_t> h_tmp8;
 };
 
 namespace {
@@ -207,21 +242,50 @@ int obs_phase(efa_ctx* c, int M, long P, double* ym_dev, double* Yp_dev, const d
   const long R = P + extra;
   const size_t dP = (size_t)P * sizeof(double);
 
-  EFA_TRY(h2d(c, c->ob_val, ob_value, dP));
-  EFA_TRY(h2d(c, c->ob_err, ob_error, dP));
-  EFA_TRY(h2d(c, c->ob_asm, ob_assim, (size_t)P));
-  if (loc_mode == EFA_LOC_GC) {
-    EFA_TRY(h2d(c, c->ob_lat, ob_lat, dP));
-    EFA_TRY(h2d(c, c->ob_lon, ob_lon, dP));
-    EFA_TRY(h2d(c, c->ob_hw, ob_hw, dP));
+  // per-ob inputs: [value | error | lat | lon | halfwidth | assim bytes] in one allocation, one H2D from pinned memory
+  {
+    const bool gc = loc_mode == EFA_LOC_GC;
+    const size_t slot = ((size_t)P * sizeof(double) + 255) & ~(size_t)255;
+    const size_t total = 6 * slot;
+    EFA_TRY(c->ob_pack.reserve(total));
+    EFA_TRY(c->pin_in.reserve(total));
+    char* hb = static_cast<char*>(c->pin_in.p);
+    char* db = static_cast<char*>(c->ob_pack.p);
+    std::memcpy(hb, ob_value, dP);
+    std::memcpy(hb + slot, ob_error, dP);
+    if (gc) {
+      std::memcpy(hb + 2 * slot, ob_lat, dP);
+      std::memcpy(hb + 3 * slot, ob_lon, dP);
+      std::memcpy(hb + 4 * slot, ob_hw, dP);
+    }
+    std::memcpy(hb + 5 * slot, ob_assim, (size_t)P);
+    c->ob_val.carve(db, slot);
+    c->ob_err.carve(db + slot, slot);
+    c->ob_lat.carve(db + 2 * slot, slot);
+    c->ob_lon.carve(db + 3 * slot, slot);
+    c->ob_hw.carve(db + 4 * slot, slot);
+    c->ob_asm.carve(db + 5 * slot, slot);
+    if (gc) {
+      EFA_HIP(hipMemcpyAsync(db, hb, total, hipMemcpyHostToDevice, c->stream));
+    } else {
+      EFA_HIP(hipMemcpyAsync(db, hb, 2 * slot, hipMemcpyHostToDevice, c->stream));
+      EFA_HIP(hipMemcpyAsync(db + 5 * slot, hb + 5 * slot, (size_t)P, hipMemcpyHostToDevice, c->stream));
+    }
   }
   EFA_TRY(c->Ye_rec.reserve((size_t)P * M * sizeof(double)));
   EFA_TRY(c->coef.reserve((size_t)P * kCoefStride * sizeof(double)));
-  EFA_TRY(c->d_prior_mean.reserve(dP));
-  EFA_TRY(c->d_prior_var.reserve(dP));
-  EFA_TRY(c->d_post_mean.reserve(dP));
-  EFA_TRY(c->d_post_var.reserve(dP));
-  EFA_TRY(c->d_assimilated.reserve((size_t)P));
+  // per-ob diagnostics: [prior_mean | prior_var | post_mean | post_var | assimilated bytes], one D2H at the end
+  const size_t oslot = ((size_t)P * sizeof(double) + 255) & ~(size_t)255;
+  {
+    EFA_TRY(c->out_pack.reserve(5 * oslot));
+    EFA_TRY(c->pin_out.reserve(5 * oslot));
+    char* db = static_cast<char*>(c->out_pack.p);
+    c->d_prior_mean.carve(db, oslot);
+    c->d_prior_var.carve(db + oslot, oslot);
+    c->d_post_mean.carve(db + 2 * oslot, oslot);
+    c->d_post_var.carve(db + 3 * oslot, oslot);
+    c->d_assimilated.carve(db + 4 * oslot, oslot);
+  }
   EFA_TRY(c->Yw.reserve((size_t)R * M * sizeof(double)));
   EFA_TRY(c->ymw.reserve((size_t)R * sizeof(double)));
 
@@ -375,19 +439,21 @@ int obs_phase(efa_ctx* c, int M, long P, double* ym_dev, double* Yp_dev, const d
   if (c->timing) EFA_HIP(hipEventRecord(c->ev[1], s));
 
   // diagnostics back to the caller (ensrf.py:66,70,75,146-149)
-  c->h_tmp.resize((size_t)P * 2);
-  c->h_tmp8.resize((size_t)P);
-  if (prior_mean) EFA_HIP(hipMemcpyAsync(prior_mean, c->d_prior_mean.p, dP, hipMemcpyDeviceToHost, s));
-  if (prior_var) EFA_HIP(hipMemcpyAsync(prior_var, c->d_prior_var.p, dP, hipMemcpyDeviceToHost, s));
-  EFA_HIP(hipMemcpyAsync(c->h_tmp.data(), c->d_post_mean.p, dP, hipMemcpyDeviceToHost, s));
-  EFA_HIP(hipMemcpyAsync(c->h_tmp.data() + P, c->d_post_var.p, dP, hipMemcpyDeviceToHost, s));
-  EFA_HIP(hipMemcpyAsync(c->h_tmp8.data(), c->d_assimilated.p, (size_t)P, hipMemcpyDeviceToHost, s));
+  EFA_HIP(hipMemcpyAsync(c->pin_out.p, c->out_pack.p, 4 * oslot + (size_t)P, hipMemcpyDeviceToHost, s));
   EFA_HIP(hipStreamSynchronize(s));
-  for (long k = 0; k < P; ++k) {
-    if (assimilated) assimilated[k] = c->h_tmp8[k];
-    if (c->h_tmp8[k]) {
-      if (post_mean) post_mean[k] = c->h_tmp[k];
-      if (post_var) post_var[k] = c->h_tmp[P + k];
+  {
+    const char* hb = static_cast<const char*>(c->pin_out.p);
+    if (prior_mean) std::memcpy(prior_mean, hb, dP);
+    if (prior_var) std::memcpy(prior_var, hb + oslot, dP);
+    const double* pm = reinterpret_cast<const double*>(hb + 2 * oslot);
+    const double* pv = reinterpret_cast<const double*>(hb + 3 * oslot);
+    const uint8_t* as = reinterpret_cast<const uint8_t*>(hb + 4 * oslot);
+    for (long k = 0; k < P; ++k) {
+      if (assimilated) assimilated[k] = as[k];
+      if (as[k]) {
+        if (post_mean) post_mean[k] = pm[k];
+        if (post_var) post_var[k] = pv[k];
+      }
     }
   }
   if (c->timing) {
@@ -623,7 +689,9 @@ int efa_ctx_destroy(efa_ctx* c) {
   if (!c) return EFA_OK;
   (void)hipSetDevice(c->device);
   if (c->stream) (void)hipStreamSynchronize(c->stream);
-  DevBuf* bufs[] = {&c->Ye_rec, &c->coef, &c->ob_val, &c->ob_err, &c->ob_asm, &c->ob_lat, &c->ob_lon, &c->ob_hw,
+  c->pin_in.release();
+  c->pin_out.release();
+  DevBuf* bufs[] = {&c->ob_pack, &c->out_pack, &c->Ye_rec, &c->coef, &c->ob_val, &c->ob_err, &c->ob_asm, &c->ob_lat, &c->ob_lon, &c->ob_hw,
                     &c->d_prior_mean, &c->d_prior_var, &c->d_post_mean, &c->d_post_var, &c->d_assimilated,
                     &c->Yw, &c->ymw, &c->traj, &c->tw_mat, &c->status, &c->dbg, &c->W, &c->gc_cnt, &c->gc_ub, &c->gc_order, &c->gc_off, &c->gc_idx, &c->gc_wts, &c->gc_pairs, &c->glat, &c->glon, &c->xm_ws, &c->fs_idx, &c->fs_wts, &c->f_glat, &c->f_glon, &c->f_sl, &c->f_cl, &c->f_valids, &c->f_var, &c->f_time, &c->f_lat, &c->f_lon, &c->f_near, &c->f_idx, &c->f_wts, &c->f_status, &c->h_xm, &c->h_Xp, &c->h_ym, &c->h_Yp};
   for (DevBuf* b : bufs) b->release();
