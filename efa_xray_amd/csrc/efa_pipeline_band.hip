@@ -152,6 +152,20 @@ __global__ __launch_bounds__(kGT) void k_pipe_band(const PipeArgs a) {
   do {                              \
   } while (0)
 #endif
+#ifdef EFA_PIPE_BLOCKTIME  /* wait accounting of the leader's waves: s_memtime around the polls (perturbs the loop a little) */
+#define EFA_WAIT_T0(t) const long t = (long)__builtin_amdgcn_s_memtime()
+#define EFA_WAIT_ADD(acc, t) acc += (long)__builtin_amdgcn_s_memtime() - (t)
+#define EFA_WAIT_DECL(...) long __VA_ARGS__
+#define EFA_WAIT_OUT(cond, row, slot, v)                                         \
+  do {                                                                            \
+    if (a.dbg != nullptr && (cond)) a.dbg[(size_t)(own0 + (row)) * 8 + (slot)] = (u64)(v); \
+  } while (0)
+#else
+#define EFA_WAIT_T0(t) do { } while (0)
+#define EFA_WAIT_ADD(acc, t) do { } while (0)
+#define EFA_WAIT_DECL(...) do { } while (0)
+#define EFA_WAIT_OUT(cond, row, slot, v) do { } while (0)
+#endif
 #if defined(EFA_PIPE_STAMPS) || defined(EFA_PIPE_BLOCKTIME)
 #define EFA_EXP(bit) ((a.debug & (bit)) != 0)  /* timing experiments (diagnostic builds only): results are wrong */
 #else
@@ -293,12 +307,15 @@ __global__ __launch_bounds__(kGT) void k_pipe_band(const PipeArgs a) {
       const double val_l = f_ob ? a.ob_value[own0 + lane] : 0.0;
       const u64 asm_mask = __ballot(f_ob ? (a.ob_assim[own0 + lane] != 0) : false);
       double l_xm = 0.0;
+      EFA_WAIT_DECL(fw_ye = 0);
       for (int b = 0; b < nbands && !failed; ++b) {
         // the band's ye rows are in the ring once every vector wave has added its tiles (4 per band)
+        EFA_WAIT_T0(tf0);
         if (!wait_gt(&ctl[cYe], 4 * (b + 1) - 1, true)) {
           failed = true;
           break;
         }
+        EFA_WAIT_ADD(fw_ye, tf0);
         const int s1 = (nb - kBand * b < kBand) ? nb - kBand * b : kBand;
         for (int s = 0; s < s1; ++s) {
           const int st = kBand * b + s;
@@ -359,6 +376,7 @@ __global__ __launch_bounds__(kGT) void k_pipe_band(const PipeArgs a) {
       }
       pm[kRowsWG + lane] = xmv;  // obs-space means of all 64 rows after the block, back to the vector waves
       EFA_BLOCKSTAMP(lane == 0, 2);
+      EFA_WAIT_OUT(lane == 0, 2, 5, fw_ye);
       __syncthreads();  // B3: done with the pivot's records
       barriers_left = 0;
       if (!failed) follow(own1, P);
@@ -653,6 +671,7 @@ __global__ __launch_bounds__(kGT) void k_pipe_band(const PipeArgs a) {
         for (int v = 0; v < 4; ++v) xt[J][v] = Yt[(size_t)(16 * v + 4 * lr + wave) * SP + 16 * J + lc];
       __syncthreads();  // B2: G complete; the tile region now belongs to the pivot wave's records
       barriers_left = 1;
+      EFA_WAIT_DECL(w_park = 0, w_linv = 0, w_ring = 0, w_ye = 0);
       for (int b = 0; b < nbands; ++b) {
         const int r0 = kBand * b;
         const int s1 = (nb - r0 < kBand) ? nb - r0 : kBand;
@@ -679,10 +698,16 @@ __global__ __launch_bounds__(kGT) void k_pipe_band(const PipeArgs a) {
         }
         if (lane == 0) __hip_atomic_fetch_add(&ctl[cPark], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         // (2) YE = L^-1 Y once every wave has parked and the pivot wave has finished the band
-        if (!wait_gt(&ctl[cPark], 4 * (b + 1) - 1, false) || !wait_gt(&ctl[cLinv], b, true)) {
+        EFA_WAIT_T0(tw0);
+        const bool ok_park = wait_gt(&ctl[cPark], 4 * (b + 1) - 1, false);
+        EFA_WAIT_ADD(w_park, tw0);
+        EFA_WAIT_T0(tw1);
+        if (!ok_park || !wait_gt(&ctl[cLinv], b, true)) {
           bailed = true;
           break;
         }
+        EFA_WAIT_ADD(w_linv, tw1);
+        EFA_WAIT_T0(tw2);
         // ring slots of this band are those of the band kRingG obs earlier: every consumer must be through with them
         if (b >= kRingG / kBand) {
           const int need = (int)(own0 + kBand * (b - kRingG / kBand) + kBand - 1);
@@ -694,6 +719,7 @@ __global__ __launch_bounds__(kGT) void k_pipe_band(const PipeArgs a) {
           }
           if (bailed) break;
         }
+        EFA_WAIT_ADD(w_ring, tw2);
         {
           const double* la = LinvA + (size_t)b * kBand * 16;
           double aop[kBand / 4];
@@ -718,10 +744,12 @@ __global__ __launch_bounds__(kGT) void k_pipe_band(const PipeArgs a) {
         }
         if (lane == 0) __hip_atomic_fetch_add(&ctl[cYe], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         // (3) the band applied to all 16 rows of this wave: X -= KB YE (rank s1 <= 8)
+        EFA_WAIT_T0(tw3);
         if (!wait_gt(&ctl[cYe], 4 * (b + 1) - 1, false)) {
           bailed = true;
           break;
         }
+        EFA_WAIT_ADD(w_ye, tw3);
 #pragma unroll
         for (int q = 0; q < kBand / 4; ++q) {
           const int st = r0 + 4 * q + lr;        // this lane's K slice: step st
@@ -737,6 +765,11 @@ __global__ __launch_bounds__(kGT) void k_pipe_band(const PipeArgs a) {
         }
         if (lane == 0) g_ctl_set(&ctl[cProg + wave], (int)(own0 + r0 + s1 - 1));  // ring slots up to here consumed
       }
+      EFA_BLOCKSTAMP(wave == 0 && lane == 0, 6);
+      EFA_WAIT_OUT(wave == 0 && lane == 0, 1, 5, w_park);
+      EFA_WAIT_OUT(wave == 0 && lane == 0, 1, 6, w_linv);
+      EFA_WAIT_OUT(wave == 0 && lane == 0, 1, 7, w_ring);
+      EFA_WAIT_OUT(wave == 0 && lane == 0, 2, 6, w_ye);
       __syncthreads();  // B3: every wave is done with the pivot's records; the tile region is free again
       barriers_left = 0;
       if (bailed) break;

@@ -40,4 +40,10 @@ if gram == 2:
     c1 = [t[64 * b, 0] - t[64 * b, 5] for b in range(1, nb)]
     print("  hand-over split: last record in ring -> followers done %6.0f | park + B1 %6.0f | Gram, tile load, B2, band load %6.0f"
           % (np.median(a), np.median(b1), np.median(c1)))
+    med = lambda f: np.median([f(b) for b in range(1, nb)])
+    print("  leader block: pivot start -> pivot end %6.0f | -> vector wave 0 through its bands %6.0f | -> last record forwarded %6.0f"
+          % (med(lambda b: t[64 * b, 1] - t[64 * b, 0]), med(lambda b: t[64 * b, 6] - t[64 * b, 0]), med(lambda b: t[64 * b, 2] - t[64 * b, 0])))
+    print("  vector wave 0 waits per block: rows parked %6.0f | pivot's band %6.0f | ring slots %6.0f | YE complete %6.0f ; forwarder waits for YE %6.0f"
+          % (med(lambda b: t[64 * b + 1, 5]), med(lambda b: t[64 * b + 1, 6]), med(lambda b: t[64 * b + 1, 7]), med(lambda b: t[64 * b + 2, 6]),
+             med(lambda b: t[64 * b + 2, 5])))
 ctx.set_option("pipe_debug", 0); ctx.set_option("path", 0); ctx.set_option("gram", 2)
