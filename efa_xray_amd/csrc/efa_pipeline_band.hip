@@ -110,7 +110,7 @@ struct BandShape {
 template <int NC>
 __global__ __launch_bounds__(kGT) void k_pipe_band(const PipeArgs a) {
   using Sh = BandShape<NC>;
-  constexpr int PAD = Sh::PAD, TS = Sh::TS, SP = Sh::SP, SPB = Sh::SPB, UREG = Sh::UREG;
+  constexpr int PAD = Sh::PAD, TS = Sh::TS, SP = Sh::SP, UREG = Sh::UREG;
   constexpr int EPL = (TS + 63) / 64;
   constexpr int NJ = (PAD + 15) / 16;  // accumulator tiles per vector wave in the block's matrix-core layout
   extern __shared__ __align__(16) double lds[];
@@ -660,110 +660,88 @@ __global__ __launch_bounds__(kGT) void k_pipe_band(const PipeArgs a) {
       __syncthreads();  // B1: tile and parked means complete
       EFA_BLOCKSTAMP(wave == 0 && lane == 0, 5);
       form_gram();
-      // For the block the rows change layout: wave w re-reads the 16 rows it has just parked (rows 4 rho + w,
-      // rho = 0..15) as NJ accumulator tiles of v_mfma_f64_16x16x4_f64: register v of tile J in lane l is member
-      // 16 J + (l & 15) of tile row rho = 4 v + (l >> 4).
+      // For the block the rows change layout: wave w takes block rows 16 w .. 16 w + 15 as NJ accumulator tiles of
+      // v_mfma_f64_16x16x4_f64: register v of tile J in lane l is member 16 J + (l & 15) of block row
+      // 16 w + 4 v + (l >> 4).  A band's four rows are then register v = (band & 3) of ONE wave, already in the
+      // B-operand layout (k = lane row, j = lane column): that wave -- the band's OWNER -- forms YE = L^-1 Y for all
+      // column tiles straight from its registers, publishes the rows in the ring and applies the band to its own tile
+      // from the same registers.  Nothing on this chain waits for another vector wave (no parking, no second counter);
+      // the three other waves take the band from the ring when the owner's flag says it is there.
+      static_assert(kBand == 4, "band ownership: four bands per 16-row tile");
       v4f64 xt[NJ];
       const int lr = lane >> 4, lc = lane & 15;
 #pragma unroll
       for (int J = 0; J < NJ; ++J)
 #pragma unroll
-        for (int v = 0; v < 4; ++v) xt[J][v] = Yt[(size_t)(16 * v + 4 * lr + wave) * SP + 16 * J + lc];
+        for (int v = 0; v < 4; ++v) xt[J][v] = Yt[(size_t)(16 * wave + 4 * v + lr) * SP + 16 * J + lc];
       __syncthreads();  // B2: G complete; the tile region now belongs to the pivot wave's records
       barriers_left = 1;
       EFA_WAIT_DECL(w_park = 0, w_linv = 0, w_ring = 0, w_ye = 0);
-      for (int b = 0; b < nbands; ++b) {
-        const int r0 = kBand * b;
-        const int s1 = (nb - r0 < kBand) ? nb - r0 : kBand;
-        double* yb = Yb + (size_t)(b & 1) * kBand * SPB;
-        // (1) park the band's rows (current through the previous band).  Band row s = 4 i + w is block row 4 rho + w
-        //     with rho = r0/4 + i: this wave holds it in register v = rho/4, lane row lr = rho%4.
+      for (int b4 = 0; b4 < nbands && !bailed; b4 += 4) {
+        const bool owner = (b4 >> 2) == wave;
 #pragma unroll
-        for (int i = 0; i < kBand / 4; ++i) {
-          const int rho = (r0 >> 2) + i;
-          if (lr == (rho & 3)) {
-            double* dst = yb + (size_t)(4 * i + wave) * SPB + lc;
-            switch (rho >> 2) {
-#define EFA_PARK_CASE(V)                                           \
-  case V:                                                          \
-    _Pragma("unroll") for (int J = 0; J < NJ; ++J) dst[16 * J] = xt[J][V]; \
-    break;
-              EFA_PARK_CASE(0)
-              EFA_PARK_CASE(1)
-              EFA_PARK_CASE(2)
-              EFA_PARK_CASE(3)
-#undef EFA_PARK_CASE
-            }
-          }
-        }
-        if (lane == 0) __hip_atomic_fetch_add(&ctl[cPark], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-        // (2) YE = L^-1 Y once every wave has parked and the pivot wave has finished the band
-        EFA_WAIT_T0(tw0);
-        const bool ok_park = wait_gt(&ctl[cPark], 4 * (b + 1) - 1, false);
-        EFA_WAIT_ADD(w_park, tw0);
-        EFA_WAIT_T0(tw1);
-        if (!ok_park || !wait_gt(&ctl[cLinv], b, true)) {
-          bailed = true;
-          break;
-        }
-        EFA_WAIT_ADD(w_linv, tw1);
-        EFA_WAIT_T0(tw2);
-        // ring slots of this band are those of the band kRingG obs earlier: every consumer must be through with them
-        if (b >= kRingG / kBand) {
-          const int need = (int)(own0 + kBand * (b - kRingG / kBand) + kBand - 1);
-          while (min_prog() < need) {
-            if (g_ctl(&ctl[cBail]) != 0 || --budget <= 0 || ((budget & 15) == 0 && EFA_TIMED_OUT())) {
+        for (int vb = 0; vb < 4; ++vb) {  // vb = band & 3: the owner's register holding the band's rows (static index)
+          const int b = b4 + vb;
+          if (b >= nbands) break;
+          const int r0 = kBand * b;
+          const int s1 = (nb - r0 < kBand) ? nb - r0 : kBand;
+          // ring slots of this band are those of the band kRingG obs earlier: every consumer must be through with them
+          // (checked by the owner before it writes; the others only read)
+          v4f64 yet[NJ];
+          if (owner) {
+            EFA_WAIT_T0(tw1);
+            if (!wait_gt(&ctl[cLinv], b, true)) {  // the pivot wave has finished the band
               bailed = true;
               break;
             }
-          }
-          if (bailed) break;
-        }
-        EFA_WAIT_ADD(w_ring, tw2);
-        {
-          const double* la = LinvA + (size_t)b * kBand * 16;
-          double aop[kBand / 4];
-#pragma unroll
-          for (int q = 0; q < kBand / 4; ++q) aop[q] = la[(size_t)(4 * q + lr) * 16 + lc];  // A[s = lc][t = 4 q + lr]
-#pragma unroll
-          for (int jt = 0; jt < 2; ++jt) {
-            const int J = wave + 4 * jt;  // this wave's column tiles
-            if (J < NJ) {
-              v4f64 ye = {0.0, 0.0, 0.0, 0.0};
-#pragma unroll
-              for (int q = 0; q < kBand / 4; ++q)
-                ye = __builtin_amdgcn_mfma_f64_16x16x4f64(aop[q], yb[(size_t)(4 * q + lr) * SPB + 16 * J + lc], ye, 0, 0, 0);
-              // D[s = 4 v + lr][col = lc]: rows s < kBand are ye_{r0+s}
-#pragma unroll
-              for (int v = 0; v < kBand / 4; ++v) {
-                const int s = 4 * v + lr;
-                if (16 * J + lc < PAD) ring[(size_t)((own0 + r0 + s) % kRingG) * TS + 16 * J + lc] = ye[v];
+            EFA_WAIT_ADD(w_linv, tw1);
+            EFA_WAIT_T0(tw2);
+            if (b >= kRingG / kBand) {
+              const int need = (int)(own0 + kBand * (b - kRingG / kBand) + kBand - 1);
+              while (min_prog() < need) {
+                if (g_ctl(&ctl[cBail]) != 0 || --budget <= 0 || ((budget & 15) == 0 && EFA_TIMED_OUT())) {
+                  bailed = true;
+                  break;
+                }
               }
+              if (bailed) break;
+            }
+            EFA_WAIT_ADD(w_ring, tw2);
+            const double aop = LinvA[(size_t)b * kBand * 16 + (size_t)lr * 16 + lc];  // A[s = lc][t = lr]
+#pragma unroll
+            for (int J = 0; J < NJ; ++J) {
+              const v4f64 z = {0.0, 0.0, 0.0, 0.0};
+              yet[J] = __builtin_amdgcn_mfma_f64_16x16x4f64(aop, xt[J][vb], z, 0, 0, 0);
+            }
+            // D[s = 4 v + lr][col = lc]: register 0 holds ye_{r0 + lr}, which is also B[k = lr][j = lc] of the update
+#pragma unroll
+            for (int J = 0; J < NJ; ++J)
+              if (16 * J + lc < PAD) ring[(size_t)((own0 + r0 + lr) % kRingG) * TS + 16 * J + lc] = yet[J][0];
+            if (lane == 0) g_ctl_set(&ctl[cYe], 4 * (b + 1));  // the forwarder and the other vector waves may read the band
+          } else {
+            EFA_WAIT_T0(tw3);
+            if (!wait_gt(&ctl[cYe], 4 * (b + 1) - 1, false)) {
+              bailed = true;
+              break;
+            }
+            EFA_WAIT_ADD(w_ye, tw3);
+          }
+          // the band applied to this wave's 16 rows: X -= KB YE (rank s1 <= 4); A[i][k = lr] = kb of block row 16 w + i
+          {
+            const int st = r0 + lr;  // this lane's K slice: step st
+            const bool valid = lr < s1;
+            double av = s_gk[(valid ? st : r0) * kRowsWG + 16 * wave + lc].y;
+            av = valid ? -av : 0.0;
+            const double* bs = ring + (size_t)((own0 + (valid ? st : r0)) % kRingG) * TS;
+#pragma unroll
+            for (int J = 0; J < NJ; ++J) {
+              double bv = owner ? yet[J][0] : bs[16 * J + lc];
+              bv = valid ? bv : 0.0;
+              xt[J] = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv, xt[J], 0, 0, 0);
             }
           }
+          if (lane == 0) g_ctl_set(&ctl[cProg + wave], (int)(own0 + r0 + s1 - 1));  // ring slots up to here consumed
         }
-        if (lane == 0) __hip_atomic_fetch_add(&ctl[cYe], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-        // (3) the band applied to all 16 rows of this wave: X -= KB YE (rank s1 <= 8)
-        EFA_WAIT_T0(tw3);
-        if (!wait_gt(&ctl[cYe], 4 * (b + 1) - 1, false)) {
-          bailed = true;
-          break;
-        }
-        EFA_WAIT_ADD(w_ye, tw3);
-#pragma unroll
-        for (int q = 0; q < kBand / 4; ++q) {
-          const int st = r0 + 4 * q + lr;        // this lane's K slice: step st
-          const bool valid = (4 * q + lr) < s1;
-          double av = s_gk[(valid ? st : r0) * kRowsWG + 4 * lc + wave].y;  // A[rho = lc][s]: kb of block row 4 rho + w
-          av = valid ? -av : 0.0;
-          const double* bs = ring + (size_t)((own0 + (valid ? st : r0)) % kRingG) * TS;
-#pragma unroll
-          for (int J = 0; J < NJ; ++J) {
-            const double bv = valid ? bs[16 * J + lc] : 0.0;
-            xt[J] = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv, xt[J], 0, 0, 0);
-          }
-        }
-        if (lane == 0) g_ctl_set(&ctl[cProg + wave], (int)(own0 + r0 + s1 - 1));  // ring slots up to here consumed
       }
       EFA_BLOCKSTAMP(wave == 0 && lane == 0, 6);
       EFA_WAIT_OUT(wave == 0 && lane == 0, 1, 5, w_park);
@@ -773,12 +751,18 @@ __global__ __launch_bounds__(kGT) void k_pipe_band(const PipeArgs a) {
       __syncthreads();  // B3: every wave is done with the pivot's records; the tile region is free again
       barriers_left = 0;
       if (bailed) break;
-      // back to the follower layout through the tile (each wave reads only rows it wrote itself)
+      // back to the follower layout through the tile: rows come back from other waves, so the four vector waves
+      // meet at an LDS counter between writing and reading (the other waves have left for their follower roles)
 #pragma unroll
       for (int J = 0; J < NJ; ++J)
 #pragma unroll
         for (int v = 0; v < 4; ++v)
-          if (16 * J + lc < PAD) Yt[(size_t)(16 * v + 4 * lr + wave) * SP + 16 * J + lc] = xt[J][v];
+          if (16 * J + lc < PAD) Yt[(size_t)(16 * wave + 4 * v + lr) * SP + 16 * J + lc] = xt[J][v];
+      if (lane == 0) __hip_atomic_fetch_add(&ctl[cPark], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+      if (!wait_gt(&ctl[cPark], kVW - 1, false)) {
+        bailed = true;
+        break;
+      }
 #pragma unroll
       for (int c = 0; c < NC; ++c) {
         const double2 v = *reinterpret_cast<const double2*>(Yt + (size_t)i_loc * SP + 2 * PLg * c + 2 * j);
