@@ -294,6 +294,12 @@ __global__ __launch_bounds__(kGT) void k_pipe_band(const PipeArgs a) {
     };
     follow(0, (own0 < P) ? own0 : P);
     EFA_BLOCKSTAMP(lane == 0 && leads, 3);
+#ifdef EFA_PIPE_BLOCKTIME
+    {
+      const int mp = min_prog();  // all lanes: the quad minimum goes through DPP
+      EFA_WAIT_OUT(lane == 0 && leads, 3, 5, (long)(own0 - 1) - (long)mp);  // records still to be applied when the last one is in the ring
+    }
+#endif
     if (leads && !failed) {
       __syncthreads();  // B1: the vector waves have parked their rows in the tile
       form_gram();

@@ -37,11 +37,22 @@ typedef double v4f64 __attribute__((ext_vector_type(4)));
 constexpr int kThreadsT = 64 * EFA_T_WAVES;  // waves per workgroup, sharing its LDS copy of [T|w]
 constexpr bool kPrefetchT = EFA_T_PREFETCH != 0;
 
-template <int NU>
+// Column tiling of the product.  Perturbation form (!FUSED): M member columns plus the column of w (the mean
+// increment): NU/2 + 1 tiles of 16.  Member form (FUSED: prior members in, posterior members out) needs no
+// separate w column -- posterior_j = mean + sum_k Xp_k (T_kj + w_k), so w is folded into the LDS image of T --
+// and when the last 16-column tile would hold at most four members (M % 16 in 1..4, i.e. HALF with NU odd) those
+// columns are done by ONE v_mfma_f64_4x4x4_4b_f64 per K step (17 cycles instead of 64) over the same A operand:
+// its four 4 x 4 x 4 blocks are the tile's four row groups, A[blk][i][k] sits in lane 16 k + 4 blk + i = 16 k + row
+// exactly as in the 16 x 16 x 4 instruction, B[blk][k][j] in lane 16 k + 4 blk + j, D[blk][i][j] in lane
+// 16 i + 4 blk + j (tools/mfma44_layout_probe.hip).  M = 100: 6 x 64 + 17 cycles per K step instead of 7 x 64.
+template <int NU, bool FUSED, bool HALF>
 struct TShape {
-  static constexpr int NT = NU / 2 + 1;          // 16*NT >= M+1 for every M <= 8*NU
+  static constexpr bool NARROW = FUSED && HALF && (NU & 1);
+  static constexpr int NT = !FUSED ? NU / 2 + 1 : (NARROW ? NU / 2 : (NU + 1) / 2);
+  static constexpr int NTA = NT > 0 ? NT : 1;    // array extent (NT = 0: M <= 4 in member form)
   static constexpr int kSteps = 2 * NU;          // K steps of 4 members
-  static constexpr size_t lds_doubles = (size_t)kSteps * NT * 64;
+  static constexpr size_t wide_doubles = (size_t)kSteps * NT * 64;
+  static constexpr size_t lds_doubles = wide_doubles + (NARROW ? (size_t)kSteps * 64 : 0);
 };
 
 // Loads of one tile are branch-free (clamped addresses; the partial last chunk is zeroed
@@ -79,26 +90,32 @@ __device__ __forceinline__ void load_tile(const double* __restrict__ X, long row
 
 template <int NU, bool FUSED, bool HALF, bool AL>
 __global__ __launch_bounds__(kThreadsT) void k_transform(const TransformArgs p) {
-  using Sh = TShape<NU>;
+  using Sh = TShape<NU, FUSED, HALF>;
   constexpr int NT = Sh::NT;
-  extern __shared__ __align__(16) double Bs[];  // [(u*2+h)*NT + t][64]
+  constexpr bool NARROW = Sh::NARROW;
+  extern __shared__ __align__(16) double Bs[];  // [(u*2+h)*NT + t][64], then the narrow tile's [(u*2+h)][64]
   const int M = p.M;
   const int tid = threadIdx.x;
 
-  // Stage [T | w] in MFMA-B order: Bs[step s=(u,h)][t][lane (g,n)] = Text[8u+2g+h][16t+n]
+  // Stage [T | w] (member form: T + w 1^T) in MFMA-B order: Bs[step s=(u,h)][t][lane (g,n)] = Text[8u+2g+h][16t+n]
   for (int i = tid; i < (int)Sh::lds_doubles; i += kThreadsT) {
     const int l = i & 63;
-    const int st = i >> 6;
-    const int t = st % NT;
-    const int s = st / NT;
-    const int u = s >> 1, h = s & 1;
     const int g = l >> 4, n = l & 15;
+    int s, j;
+    if (i < (int)Sh::wide_doubles) {
+      const int st = i >> 6;
+      s = st / Sh::NTA;
+      j = 16 * (st % Sh::NTA) + n;
+    } else {  // narrow tile: B[blk][k = g][j = l & 3] for every block
+      s = (i - (int)Sh::wide_doubles) >> 6;
+      j = 16 * NT + (l & 3);
+    }
+    const int u = s >> 1, h = s & 1;
     const int m = (HALF && u == NU - 1) ? (h == 0 ? 8 * u + g : M) : 8 * u + 2 * g + h;  // (row M: never used, stays 0)
-    const int j = 16 * t + n;
     double v = 0.0;
     if (m < M) {
-      if (j < M) v = p.T[(size_t)m * M + j];
-      else if (j == M) v = p.w[m];
+      if (j < M) v = FUSED ? p.T[(size_t)m * M + j] + p.w[m] : p.T[(size_t)m * M + j];
+      else if (j == M && !FUSED) v = p.w[m];
     }
     Bs[i] = v;
   }
@@ -158,9 +175,10 @@ __global__ __launch_bounds__(kThreadsT) void k_transform(const TransformArgs p) 
       a[2 * NU - 1] = last_ok1 ? a[2 * NU - 1] - rmean : 0.0;
     }
 
-    v4f64 acc[NT];
+    v4f64 acc[Sh::NTA];
+    double accn = 0.0;  // narrow tile: D[row 4 ((lane >> 2) & 3) + (lane >> 4)][col 16 NT + (lane & 3)]
 #pragma unroll
-    for (int t = 0; t < NT; ++t) acc[t] = (v4f64){0.0, 0.0, 0.0, 0.0};
+    for (int t = 0; t < Sh::NTA; ++t) acc[t] = (v4f64){0.0, 0.0, 0.0, 0.0};
 #pragma unroll
     for (int s = 0; s < (HALF ? 2 * NU - 1 : 2 * NU); ++s) {
 #pragma unroll
@@ -168,6 +186,7 @@ __global__ __launch_bounds__(kThreadsT) void k_transform(const TransformArgs p) 
         const double b = Bs[((size_t)s * NT + t) * 64 + lane];
         acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[s], b, acc[t], 0, 0, 0);
       }
+      if (NARROW) accn = __builtin_amdgcn_mfma_f64_4x4x4f64(a[s], Bs[Sh::wide_doubles + (size_t)s * 64 + lane], accn, 0, 0, 0);
       // keep the scheduler from hoisting all 2*NU*NT LDS reads (register blow-up)
       __builtin_amdgcn_sched_barrier(0);
     }
@@ -176,13 +195,19 @@ __global__ __launch_bounds__(kThreadsT) void k_transform(const TransformArgs p) 
     double base[4];  // posterior mean of rows 4v+g: prior mean + column M of the product
 #pragma unroll
     for (int v = 0; v < 4; ++v) {
-      double dm = 0.0;
+      if (FUSED) {
+        base[v] = __shfl(rmean, 4 * v + g, 64);  // w is folded into the image of T
+      } else {
+        double dm = 0.0;
 #pragma unroll
-      for (int t = 0; t < NT; ++t)
-        if (t == tM) dm = __shfl(acc[t][v], (lane & 48) | nM, 64);
-      const double m0 = FUSED ? __shfl(rmean, 4 * v + g, 64) : xm4[v];
-      base[v] = m0 + dm;
+        for (int t = 0; t < NT; ++t)
+          if (t == tM) dm = __shfl(acc[t][v], (lane & 48) | nM, 64);
+        base[v] = xm4[v] + dm;
+      }
     }
+    const int nrow = 4 * ((lane >> 2) & 3) + g;  // the narrow tile's row and column of this lane
+    const int ncol = 16 * NT + (lane & 3);
+    const double nval = NARROW ? __shfl(rmean, nrow, 64) + accn : 0.0;
     if (r0 + 16 <= p.nrows) {  // full tile: no row checks (wave-uniform)
 #pragma unroll
       for (int t = 0; t < NT; ++t) {
@@ -193,6 +218,7 @@ __global__ __launch_bounds__(kThreadsT) void k_transform(const TransformArgs p) 
             p.Xout[(size_t)(r0 + 4 * v + g) * M + col] = FUSED ? (base[v] + acc[t][v]) : acc[t][v];
         }
       }
+      if (NARROW && ncol < M) p.Xout[(size_t)(r0 + nrow) * M + ncol] = nval;
       if (!FUSED && n == 0) {
 #pragma unroll
         for (int v = 0; v < 4; ++v) p.xout[r0 + 4 * v + g] = base[v];
@@ -208,6 +234,7 @@ __global__ __launch_bounds__(kThreadsT) void k_transform(const TransformArgs p) 
             p.Xout[(size_t)row * M + col] = FUSED ? (base[v] + acc[t][v]) : acc[t][v];
         }
       }
+      if (NARROW && ncol < M && r0 + nrow < p.nrows) p.Xout[(size_t)(r0 + nrow) * M + ncol] = nval;
       if (!FUSED && n == 0) {
 #pragma unroll
         for (int v = 0; v < 4; ++v) {
@@ -236,8 +263,8 @@ __global__ __launch_bounds__(kThreadsT) void k_transform(const TransformArgs p) 
 
 template <int NU, bool FUSED, bool HALF, bool AL>
 hipError_t transform_launch(const TransformArgs& a, hipStream_t s) {
-  using Sh = TShape<NU>;
-  const size_t lds = Sh::lds_doubles * sizeof(double);
+  using Sh = TShape<NU, FUSED, HALF>;
+  const size_t lds = (Sh::lds_doubles ? Sh::lds_doubles : 64) * sizeof(double);
   if (lds > 64 * 1024) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_transform<NU, FUSED, HALF, AL>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);

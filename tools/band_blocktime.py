@@ -46,4 +46,6 @@ if gram == 2:
     print("  vector wave 0 waits per block: rows parked %6.0f | pivot's band %6.0f | ring slots %6.0f | YE complete %6.0f ; forwarder waits for YE %6.0f"
           % (med(lambda b: t[64 * b + 1, 5]), med(lambda b: t[64 * b + 1, 6]), med(lambda b: t[64 * b + 1, 7]), med(lambda b: t[64 * b + 2, 6]),
              med(lambda b: t[64 * b + 2, 5])))
+    print("  records still to be applied by the slowest vector wave when the last foreign record is in the ring: median %.0f (min %d, max %d)"
+          % (med(lambda b: t[64 * b + 3, 5]), min(t[64 * b + 3, 5] for b in range(1, nb)), max(t[64 * b + 3, 5] for b in range(1, nb))))
 ctx.set_option("pipe_debug", 0); ctx.set_option("path", 0); ctx.set_option("gram", 2)
