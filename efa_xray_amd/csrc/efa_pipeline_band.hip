@@ -693,7 +693,7 @@ __global__ __launch_bounds__(kGT) void k_pipe_band(const PipeArgs a) {
           const int s1 = (nb - r0 < kBand) ? nb - r0 : kBand;
           // ring slots of this band are those of the band kRingG obs earlier: every consumer must be through with them
           // (checked by the owner before it writes; the others only read)
-          v4f64 yet[NJ];
+          double ye0[NJ];  // the owner's YE tiles: register 0 of each MFMA result
           if (owner) {
             EFA_WAIT_T0(tw1);
             if (!wait_gt(&ctl[cLinv], b, true)) {  // the pivot wave has finished the band
@@ -717,12 +717,13 @@ __global__ __launch_bounds__(kGT) void k_pipe_band(const PipeArgs a) {
 #pragma unroll
             for (int J = 0; J < NJ; ++J) {
               const v4f64 z = {0.0, 0.0, 0.0, 0.0};
-              yet[J] = __builtin_amdgcn_mfma_f64_16x16x4f64(aop, xt[J][vb], z, 0, 0, 0);
+              const v4f64 yt = __builtin_amdgcn_mfma_f64_16x16x4f64(aop, xt[J][vb], z, 0, 0, 0);
+              ye0[J] = yt[0];
             }
             // D[s = 4 v + lr][col = lc]: register 0 holds ye_{r0 + lr}, which is also B[k = lr][j = lc] of the update
 #pragma unroll
             for (int J = 0; J < NJ; ++J)
-              if (16 * J + lc < PAD) ring[(size_t)((own0 + r0 + lr) % kRingG) * TS + 16 * J + lc] = yet[J][0];
+              if (16 * J + lc < PAD) ring[(size_t)((own0 + r0 + lr) % kRingG) * TS + 16 * J + lc] = ye0[J];
             if (lane == 0) g_ctl_set(&ctl[cYe], 4 * (b + 1));  // the forwarder and the other vector waves may read the band
           } else {
             EFA_WAIT_T0(tw3);
@@ -741,7 +742,7 @@ __global__ __launch_bounds__(kGT) void k_pipe_band(const PipeArgs a) {
             const double* bs = ring + (size_t)((own0 + (valid ? st : r0)) % kRingG) * TS;
 #pragma unroll
             for (int J = 0; J < NJ; ++J) {
-              double bv = owner ? yet[J][0] : bs[16 * J + lc];
+              double bv = owner ? ye0[J] : bs[16 * J + lc];
               bv = valid ? bv : 0.0;
               xt[J] = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv, xt[J], 0, 0, 0);
             }
