@@ -152,18 +152,12 @@ __global__ __launch_bounds__(kGT) void k_pipe_band(const PipeArgs a) {
   do {                              \
   } while (0)
 #endif
-#ifdef EFA_PIPE_BLOCKTIME  /* wait accounting of the leader's waves: s_memtime around the polls (perturbs the loop a little) */
-#define EFA_WAIT_T0(t) const long t = (long)__builtin_amdgcn_s_memtime()
-#define EFA_WAIT_ADD(acc, t) acc += (long)__builtin_amdgcn_s_memtime() - (t)
-#define EFA_WAIT_DECL(...) long __VA_ARGS__
+#ifdef EFA_PIPE_BLOCKTIME
 #define EFA_WAIT_OUT(cond, row, slot, v)                                         \
   do {                                                                            \
     if (a.dbg != nullptr && (cond)) a.dbg[(size_t)(own0 + (row)) * 8 + (slot)] = (u64)(v); \
   } while (0)
 #else
-#define EFA_WAIT_T0(t) do { } while (0)
-#define EFA_WAIT_ADD(acc, t) do { } while (0)
-#define EFA_WAIT_DECL(...) do { } while (0)
 #define EFA_WAIT_OUT(cond, row, slot, v) do { } while (0)
 #endif
 #if defined(EFA_PIPE_STAMPS) || defined(EFA_PIPE_BLOCKTIME)
@@ -294,6 +288,7 @@ __global__ __launch_bounds__(kGT) void k_pipe_band(const PipeArgs a) {
     };
     follow(0, (own0 < P) ? own0 : P);
     EFA_BLOCKSTAMP(lane == 0 && leads, 3);
+    EFA_WAIT_OUT(lane == 0 && leads, 4, 6, __builtin_amdgcn_s_memrealtime());  // 100 MHz, comparable across workgroups
 #ifdef EFA_PIPE_BLOCKTIME
     {
       const int mp = min_prog();  // all lanes: the quad minimum goes through DPP
@@ -313,15 +308,12 @@ __global__ __launch_bounds__(kGT) void k_pipe_band(const PipeArgs a) {
       const double val_l = f_ob ? a.ob_value[own0 + lane] : 0.0;
       const u64 asm_mask = __ballot(f_ob ? (a.ob_assim[own0 + lane] != 0) : false);
       double l_xm = 0.0;
-      EFA_WAIT_DECL(fw_ye = 0);
       for (int b = 0; b < nbands && !failed; ++b) {
         // the band's ye rows are in the ring once every vector wave has added its tiles (4 per band)
-        EFA_WAIT_T0(tf0);
         if (!wait_gt(&ctl[cYe], 4 * (b + 1) - 1, true)) {
           failed = true;
           break;
         }
-        EFA_WAIT_ADD(fw_ye, tf0);
         const int s1 = (nb - kBand * b < kBand) ? nb - kBand * b : kBand;
         for (int s = 0; s < s1; ++s) {
           const int st = kBand * b + s;
@@ -382,7 +374,7 @@ __global__ __launch_bounds__(kGT) void k_pipe_band(const PipeArgs a) {
       }
       pm[kRowsWG + lane] = xmv;  // obs-space means of all 64 rows after the block, back to the vector waves
       EFA_BLOCKSTAMP(lane == 0, 2);
-      EFA_WAIT_OUT(lane == 0, 2, 5, fw_ye);
+      EFA_WAIT_OUT(lane == 0, 4, 5, __builtin_amdgcn_s_memrealtime());
       __syncthreads();  // B3: done with the pivot's records
       barriers_left = 0;
       if (!failed) follow(own1, P);
@@ -434,6 +426,7 @@ __global__ __launch_bounds__(kGT) void k_pipe_band(const PipeArgs a) {
 #pragma unroll
       for (int o = 0; o < kBand - kEarly; ++o) gprev[o] = gamprev[o] = 0.0;
       EFA_BLOCKSTAMP(lane == 0, 0);
+      EFA_WAIT_OUT(lane == 0, 5, 5, __builtin_amdgcn_s_memrealtime());
       for (int b = 0; b < nbands && ok; ++b) {
         const int r0 = kBand * b;
         const int s1 = (nb - r0 < kBand) ? nb - r0 : kBand;  // steps of this band
@@ -654,6 +647,7 @@ __global__ __launch_bounds__(kGT) void k_pipe_band(const PipeArgs a) {
       // ---------------- this workgroup's block ----------------
 #ifdef EFA_PIPE_BLOCKTIME
       if (a.dbg != nullptr && lane == 0) a.dbg[(size_t)(own0 + wave) * 8 + 4] = __builtin_amdgcn_s_memtime();  // per vector wave
+      EFA_WAIT_OUT(wave == 0 && lane == 0, 4, 7, __builtin_amdgcn_s_memrealtime());
 #endif
 #pragma unroll
       for (int c = 0; c < NC; ++c)
@@ -682,7 +676,6 @@ __global__ __launch_bounds__(kGT) void k_pipe_band(const PipeArgs a) {
         for (int v = 0; v < 4; ++v) xt[J][v] = Yt[(size_t)(16 * wave + 4 * v + lr) * SP + 16 * J + lc];
       __syncthreads();  // B2: G complete; the tile region now belongs to the pivot wave's records
       barriers_left = 1;
-      EFA_WAIT_DECL(w_park = 0, w_linv = 0, w_ring = 0, w_ye = 0);
       for (int b4 = 0; b4 < nbands && !bailed; b4 += 4) {
         const bool owner = (b4 >> 2) == wave;
 #pragma unroll
@@ -695,13 +688,10 @@ __global__ __launch_bounds__(kGT) void k_pipe_band(const PipeArgs a) {
           // (checked by the owner before it writes; the others only read)
           double ye0[NJ];  // the owner's YE tiles: register 0 of each MFMA result
           if (owner) {
-            EFA_WAIT_T0(tw1);
             if (!wait_gt(&ctl[cLinv], b, true)) {  // the pivot wave has finished the band
               bailed = true;
               break;
             }
-            EFA_WAIT_ADD(w_linv, tw1);
-            EFA_WAIT_T0(tw2);
             if (b >= kRingG / kBand) {
               const int need = (int)(own0 + kBand * (b - kRingG / kBand) + kBand - 1);
               while (min_prog() < need) {
@@ -712,7 +702,6 @@ __global__ __launch_bounds__(kGT) void k_pipe_band(const PipeArgs a) {
               }
               if (bailed) break;
             }
-            EFA_WAIT_ADD(w_ring, tw2);
             const double aop = LinvA[(size_t)b * kBand * 16 + (size_t)lr * 16 + lc];  // A[s = lc][t = lr]
 #pragma unroll
             for (int J = 0; J < NJ; ++J) {
@@ -726,12 +715,10 @@ __global__ __launch_bounds__(kGT) void k_pipe_band(const PipeArgs a) {
               if (16 * J + lc < PAD) ring[(size_t)((own0 + r0 + lr) % kRingG) * TS + 16 * J + lc] = ye0[J];
             if (lane == 0) g_ctl_set(&ctl[cYe], 4 * (b + 1));  // the forwarder and the other vector waves may read the band
           } else {
-            EFA_WAIT_T0(tw3);
             if (!wait_gt(&ctl[cYe], 4 * (b + 1) - 1, false)) {
               bailed = true;
               break;
             }
-            EFA_WAIT_ADD(w_ye, tw3);
           }
           // the band applied to this wave's 16 rows: X -= KB YE (rank s1 <= 4); A[i][k = lr] = kb of block row 16 w + i
           {
@@ -751,10 +738,6 @@ __global__ __launch_bounds__(kGT) void k_pipe_band(const PipeArgs a) {
         }
       }
       EFA_BLOCKSTAMP(wave == 0 && lane == 0, 6);
-      EFA_WAIT_OUT(wave == 0 && lane == 0, 1, 5, w_park);
-      EFA_WAIT_OUT(wave == 0 && lane == 0, 1, 6, w_linv);
-      EFA_WAIT_OUT(wave == 0 && lane == 0, 1, 7, w_ring);
-      EFA_WAIT_OUT(wave == 0 && lane == 0, 2, 6, w_ye);
       __syncthreads();  // B3: every wave is done with the pivot's records; the tile region is free again
       barriers_left = 0;
       if (bailed) break;

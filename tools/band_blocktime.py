@@ -43,9 +43,14 @@ if gram == 2:
     med = lambda f: np.median([f(b) for b in range(1, nb)])
     print("  leader block: pivot start -> pivot end %6.0f | -> vector wave 0 through its bands %6.0f | -> last record forwarded %6.0f"
           % (med(lambda b: t[64 * b, 1] - t[64 * b, 0]), med(lambda b: t[64 * b, 6] - t[64 * b, 0]), med(lambda b: t[64 * b, 2] - t[64 * b, 0])))
-    print("  vector wave 0 waits per block: rows parked %6.0f | pivot's band %6.0f | ring slots %6.0f | YE complete %6.0f ; forwarder waits for YE %6.0f"
-          % (med(lambda b: t[64 * b + 1, 5]), med(lambda b: t[64 * b + 1, 6]), med(lambda b: t[64 * b + 1, 7]), med(lambda b: t[64 * b + 2, 6]),
-             med(lambda b: t[64 * b + 2, 5])))
     print("  records still to be applied by the slowest vector wave when the last foreign record is in the ring: median %.0f (min %d, max %d)"
           % (med(lambda b: t[64 * b + 3, 5]), min(t[64 * b + 3, 5] for b in range(1, nb)), max(t[64 * b + 3, 5] for b in range(1, nb))))
+    # absolute times (s_memrealtime, 10 ns ticks, comparable across workgroups): block b's last record forwarded -> block b+1
+    rt = lambda b, r, c: int(t[64 * b + r, c])
+    ch = [(rt(b + 1, 4, 6) - rt(b, 4, 5), rt(b + 1, 4, 7) - rt(b + 1, 4, 6), rt(b + 1, 5, 5) - rt(b + 1, 4, 7), rt(b + 1, 4, 5) - rt(b + 1, 5, 5),
+           rt(b + 1, 4, 5) - rt(b, 4, 5)) for b in range(1, nb - 1)]
+    ch = np.array(ch) * 10.0
+    print("  chain between blocks, ns (median): last record forwarded -> in the next leader's ring %5.0f | -> its vector waves at their block %5.0f"
+          " | -> its pivot starts %5.0f | -> its last record forwarded %5.0f ; block period %5.0f"
+          % tuple(np.median(ch, axis=0)))
 ctx.set_option("pipe_debug", 0); ctx.set_option("path", 0); ctx.set_option("gram", 2)
