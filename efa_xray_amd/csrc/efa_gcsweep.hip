@@ -239,8 +239,7 @@ __global__ __launch_bounds__(256, (NC * (RPL + 1) <= 30) ? EFA_GC_MINWAVES : (NC
   constexpr int L = 4;
   constexpr int S = 2 * L * NC;  // padded ye row (doubles)
   __shared__ __align__(16) double ye_s[kChunk * S];
-  __shared__ __align__(16) double wt_s[kChunk * kBlkCols];
-  __shared__ __align__(16) double cf_s[kChunk * 4];
+  __shared__ __align__(16) double2 ab_s[kChunk * kBlkCols];  // per (staged ob, column): what scales (x . ye) in the row / in its mean
   const int tid = threadIdx.x;
   const int wave = tid >> 6, lane = tid & 63;
   const int j = lane & 3, r = lane >> 2;
@@ -303,27 +302,28 @@ __global__ __launch_bounds__(256, (NC * (RPL + 1) <= 30) ? EFA_GC_MINWAVES : (NC
           ye_s[i] = (m < M) ? a.Ye[(size_t)k * a.ye_stride + m] : 0.0;
         }
       }
-      for (int i = tid; i < ne * kBlkCols; i += 256) wt_s[i] = a.wts[(size_t)c0 * kBlkCols + i];
-      if (tid < ne * 4) {
-        const int ee = tid >> 2, q = tid & 3;
-        cf_s[tid] = a.coef[(size_t)a.idx[c0 + ee] * kCoefStride + q];
+      // The gain scalars of ensrf.py:95-136 -- kcov = (x . ye)/(M-1), times the taper, /kdenom, times innov for the mean
+      // and times beta for the members -- do not depend on the state row: they are folded ONCE per (ob, column) here,
+      // A = w (1/(M-1)) (1/kdenom) beta and B = w (1/(M-1)) (1/kdenom) innov, instead of six dependent multiplications
+      // per row and observation in a loop that is bound by the number of fp64 instructions it issues.
+      for (int i = tid; i < ne * kBlkCols; i += 256) {
+        const double w = a.wts[(size_t)c0 * kBlkCols + i];
+        const double* ck = a.coef + (size_t)a.idx[c0 + i / kBlkCols] * kCoefStride;  // innov, 1/kdenom, beta, active
+        const double g = (w * rM1) * ck[1];
+        ab_s[i] = make_double2(g * ck[2], g * ck[0]);  // w == 0 (or an ob that is not assimilated): both exactly 0
       }
       __syncthreads();
       // ---- apply the chunk to this wave's 16 RPL rows
       for (int ee = 0; ee < ne; ++ee) {
-        const double w = any_live ? wt_s[ee * kBlkCols + cq] : 0.0;
-        if (__ballot(w != 0.0) == 0ull) continue;  // none of this wave's rows (dead slabs / zero taper)
+        const double2 ab = ab_s[ee * kBlkCols + cq];
+        if (!any_live || __ballot(ab.x != 0.0) == 0ull) continue;  // none of this wave's rows (dead slabs / zero taper)
         double y[2 * NC];
         lds_read_row<L, NC>(ye_s + ee * S, j, y);
-        const double* ck = cf_s + ee * 4;
 #pragma unroll
         for (int q = 0; q < RPL; ++q) {
-          const double dot = gc_dot<NC>(x[q], y);
-          double kc = dot * rM1;            // :95
-          kc = w * kc;                      // :115 (a dead row holds zeros: its dot, and so its update, is exactly 0)
-          const double km = kc * ck[1];     // :119
-          xm[q] = xm[q] + km * ck[0];       // :130
-          const double kb = ck[2] * km;     // :136
+          const double dot = gc_dot<NC>(x[q], y);        // :95 (a dead row holds zeros: its dot, and so its update, is exactly 0)
+          xm[q] = __builtin_fma(ab.y, dot, xm[q]);       // :115, :119, :130
+          const double kb = ab.x * dot;                  // :115, :119, :136
 #pragma unroll
           for (int c = 0; c < 2 * NC; ++c) x[q][c] = __builtin_fma(-kb, y[c], x[q][c]);  // :141
         }

@@ -52,7 +52,6 @@ def test_baseline_kernels_fit_their_register_budget():
     no_spill = [
         ("k_transformILi13ELb1ELb1ELb1E",),          # headline, configs[1] (M = 100, 50 -> NU 13, 7: checked below)
         ("k_transformILi7ELb1ELb1ELb1E",),
-        ("k_sweep_gcILi10ELb1ELb1ELi2E",),           # configs[2]: 80 members
         ("k_sweep_gcILi13ELb1ELb1ELi2E",),           # configs[3]: 100 members
         ("k_pipe_gramILi10E",), ("k_pipe_gramILi13E",),
         ("k_contract_f32_raILi64E",),                # configs[4]
@@ -61,6 +60,8 @@ def test_baseline_kernels_fit_their_register_budget():
     for parts in no_spill:
         k = find(*parts)
         assert k.get(".vgpr_spill_count", 0) == 0, (k[".name"], k[".vgpr_count"], k[".vgpr_spill_count"])
+    # configs[2] (80 members) at three waves per SIMD: at most one loop-invariant pair, reloaded once per group of slabs
+    assert find("k_sweep_gcILi10ELb1ELb1ELi2E").get(".vgpr_spill_count", 0) <= 2
     band = find("k_pipe_bandILi13E")                 # headline Phase A: 8 waves of up to 256 registers
     assert band.get(".vgpr_spill_count", 0) <= 2 and band[".vgpr_count"] <= 256
     # occupancy the kernels are written for (512 VGPRs per SIMD lane on gfx950)
