@@ -140,6 +140,8 @@ struct efa_ctx {
   int phase_a_kind = 0;          // 1 pipeline, 2 per-batch kernels
   DevBuf ob_pack, out_pack;  // the per-ob inputs / diagnostics below are carved out of these two allocations
   PinBuf pin_in, pin_out;    // their pinned host images: one H2D and one D2H per call
+  PinBuf pin_fs;             // pinned image of the forward-operator stencil
+  hipEvent_t ev_fs = nullptr;  // its last host-to-device copy
   DevBuf ob_val, ob_err, ob_asm, ob_lat, ob_lon, ob_hw;  // device copies [P]
   DevBuf d_prior_mean, d_prior_var, d_post_mean, d_post_var, d_assimilated;
   DevBuf Yw, ymw;  // obs block workspace [(P+M)][M], [(P+M)]
@@ -691,6 +693,8 @@ int efa_ctx_destroy(efa_ctx* c) {
   if (c->stream) (void)hipStreamSynchronize(c->stream);
   c->pin_in.release();
   c->pin_out.release();
+  c->pin_fs.release();
+  if (c->ev_fs) (void)hipEventDestroy(c->ev_fs);
   DevBuf* bufs[] = {&c->ob_pack, &c->out_pack, &c->Ye_rec, &c->coef, &c->ob_val, &c->ob_err, &c->ob_asm, &c->ob_lat, &c->ob_lon, &c->ob_hw,
                     &c->d_prior_mean, &c->d_prior_var, &c->d_post_mean, &c->d_post_var, &c->d_assimilated,
                     &c->Yw, &c->ymw, &c->traj, &c->tw_mat, &c->status, &c->dbg, &c->W, &c->gc_cnt, &c->gc_ub, &c->gc_order, &c->gc_off, &c->gc_idx, &c->gc_wts, &c->gc_pairs, &c->glat, &c->glon, &c->xm_ws, &c->fs_idx, &c->fs_wts, &c->f_glat, &c->f_glon, &c->f_sl, &c->f_cl, &c->f_valids, &c->f_var, &c->f_time, &c->f_lat, &c->f_lon, &c->f_near, &c->f_idx, &c->f_wts, &c->f_status, &c->h_xm, &c->h_Xp, &c->h_ym, &c->h_Yp};
@@ -844,14 +848,22 @@ int efa_forward_stencil_dev(efa_ctx* c, long rows, long row_offset, int M, const
   if (P == 0) return EFA_OK;
   if (!X_dev || !idx || !wts || !HX_dev) return fail(EFA_ERR_INVALID, "null pointer");
   // staging of the stencil in grow-only context buffers (a hipMalloc/hipFree pair per call costs more than the kernel)
+  // The caller's arrays are copied into pinned memory (free to be reused on return) and go to the device as ONE
+  // asynchronous copy: no stream synchronisation here.  The pinned image is reused by the next call, which first waits
+  // for this copy's event (long complete by then).
   const size_t n = (size_t)P * npt;
-  EFA_TRY(c->fs_idx.reserve(n * sizeof(int64_t)));
-  EFA_TRY(c->fs_wts.reserve(n * sizeof(double)));
-  EFA_HIP(hipMemcpyAsync(c->fs_idx.p, idx, n * sizeof(int64_t), hipMemcpyHostToDevice, c->stream));
-  EFA_HIP(hipMemcpyAsync(c->fs_wts.p, wts, n * sizeof(double), hipMemcpyHostToDevice, c->stream));
-  EFA_HIP(efa::launch_forward_stencil(rows, row_offset, M, X_dev, P, npt, c->fs_idx.as<int64_t>(), c->fs_wts.as<double>(),
-                                      HX_dev, c->stream));
-  EFA_HIP(hipStreamSynchronize(c->stream));  // the caller may reuse idx / wts on return
+  const size_t half = (n * sizeof(int64_t) + 255) & ~(size_t)255;
+  EFA_TRY(c->fs_idx.reserve(2 * half));
+  EFA_TRY(c->pin_fs.reserve(2 * half));
+  if (!c->ev_fs) EFA_HIP(hipEventCreateWithFlags(&c->ev_fs, hipEventDisableTiming));
+  else EFA_HIP(hipEventSynchronize(c->ev_fs));
+  std::memcpy(c->pin_fs.p, idx, n * sizeof(int64_t));
+  std::memcpy(static_cast<char*>(c->pin_fs.p) + half, wts, n * sizeof(double));
+  EFA_HIP(hipMemcpyAsync(c->fs_idx.p, c->pin_fs.p, half + n * sizeof(double), hipMemcpyHostToDevice, c->stream));
+  EFA_HIP(hipEventRecord(c->ev_fs, c->stream));
+  EFA_HIP(efa::launch_forward_stencil(rows, row_offset, M, X_dev, P, npt, c->fs_idx.as<int64_t>(),
+                                      reinterpret_cast<const double*>(static_cast<const char*>(c->fs_idx.p) + half), HX_dev,
+                                      c->stream));
   return EFA_OK;
 }
 
