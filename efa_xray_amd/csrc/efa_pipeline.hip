@@ -35,7 +35,8 @@
 // from a FRESH two-pass variance that the row's owner computed one step earlier, off the
 // chain; if var' < 1% of var (cancellation) it is recomputed from the updated row.
 //
-// All workgroups are co-resident (grid <= 256, one 576-thread workgroup per CU); every
+// All workgroups are co-resident (grid <= 256, one 320-thread workgroup per CU, checked against the occupancy query
+// before the launch); every
 // spin is bounded; a global abort word releases everyone; the kernel then writes nothing
 // back and the host re-runs Phase A with the per-batch kernels.
 #include "efa_device.h"

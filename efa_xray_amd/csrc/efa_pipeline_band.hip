@@ -9,22 +9,25 @@
 // pass ye_k from wave to wave (write, flag, poll, read) before ye_{k+1} can be formed.  Stage
 // timings with the production code (tools/gram_blocktime.py, profiles/r02_phase_a_stages.txt):
 // pivot alone 1 060 cycles per step, pivot waiting for its helper row 1 520 (late in 61 of 64
-// steps), vector chain 1 650, followers 950.  Here the block is cut into BANDS of 8 observations and
+// steps), vector chain 1 650, followers 950.  Here the block is cut into BANDS of 4 observations and
 // the waves exchange data once per band:
 //
-//   pivot wave   keeps the band's 8 rows of G (lane = column) in registers and runs the 8 steps of
+//   pivot wave   keeps the band's 4 rows of G (lane = column) in registers and runs the 4 steps of
 //                the Gram-space recurrence alone: chain scalars by v_readlane, the rows of the band
-//                that follow are downdated in registers.  Per step it publishes {G_kj, kb_j} and
-//                the ob's scalars; per band the inverse of the band's unit lower triangular factor
+//                that follow are downdated in registers.  Per step it publishes {G_kj, kb_j}; per band
+//                the obs' scalars and the inverse of the band's unit lower triangular factor
 //                (ye_{r0+s} = y_{r0+s} - sum_{t<s} kb^{(t)}_{r0+s} ye_{r0+t}  <=>  YE = L^-1 Y).
 //   2 G waves    hold G as matrix-core accumulator tiles (two tile columns each) and apply a
 //                band's downdates as matrix-core updates per tile (v_mfma_f64_16x16x4_f64, from the step
-//                records alone: A = -G_ki, B = kb_j and A = -kb_i, B = t_j); the tile row of the next band
-//                goes first and is handed to the pivot wave through LDS.
-//   4 vector waves  park the band's 8 rows, form YE = L^-1 Y on the matrix cores (no ye_k -> ye_{k+1}
-//                chain across waves), and apply the band to all 64 rows as one rank-8 update
-//                (A = -kb, B = YE).
-//   loader wave  forwards the band's records to global memory, as before.
+//                records alone: A = -G_ki, B = kb_j and A = -kb_i, B = t_j); the next band's rows go first
+//                and are handed to the pivot wave through LDS half a band early.
+//   4 vector waves  hold 16 consecutive block rows each as accumulator tiles.  The band's four rows are one
+//                register of ONE wave, already in B-operand layout: that wave forms YE = L^-1 Y for every
+//                column tile from its registers, publishes it in the ring and applies the band to its own
+//                tile from the same registers; the other three take the band from the ring (rank-4 update,
+//                A = -kb, B = YE).  No ye_k -> ye_{k+1} chain across waves, no rendezvous among them.
+//   loader wave  carries the obs-space means, forwards the band's records to global memory, derives the
+//                obs' diagnostics once per block.
 //
 // LDS instructions per observation step in the leading workgroup drop from ~140 to ~25, and no wave
 // waits for another inside a band.  The Gram-space cancellation guard and the fallbacks are those of
