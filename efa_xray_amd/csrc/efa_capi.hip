@@ -147,7 +147,7 @@ struct efa_ctx {
   DevBuf Yw, ymw;  // obs block workspace [(P+M)][M], [(P+M)]
   // --- state phase workspaces ---------------------------------------------
   DevBuf W;           // taper table [nb][ncol]
-  DevBuf gc_cnt, gc_ub, gc_order, gc_off, gc_idx, gc_wts, gc_pairs;  // one-pass GC sweep: CSR active lists
+  DevBuf gc_cnt, gc_ub, gc_order, gc_obtrig, gc_off, gc_idx, gc_wts, gc_pairs;  // one-pass GC sweep: CSR active lists
   long gc_active_pairs = 0;  // (column, ob) pairs with a non-zero taper in the last one-pass sweep
   DevBuf glat, glon;  // grid lat/lon [ncol]
   DevBuf xm_ws;       // means for efa_state_cycle_dev
@@ -496,6 +496,7 @@ int state_gc_onepass(efa_ctx* c, long rows, const double* xm_in, const double* X
   EFA_TRY(c->gc_cnt.reserve((size_t)nblk * sizeof(int)));
   EFA_TRY(c->gc_ub.reserve((size_t)nblk * sizeof(int)));
   EFA_TRY(c->gc_order.reserve((size_t)nblk * sizeof(int)));
+  EFA_TRY(c->gc_obtrig.reserve((size_t)P * 6 * sizeof(double)));
   EFA_TRY(c->gc_off.reserve((size_t)(nblk + 1) * sizeof(long)));
   EFA_TRY(c->gc_pairs.reserve(sizeof(unsigned long long)));
   EFA_HIP(hipMemsetAsync(c->gc_pairs.p, 0, sizeof(unsigned long long), s));
@@ -507,8 +508,8 @@ int state_gc_onepass(efa_ctx* c, long rows, const double* xm_in, const double* X
   EFA_TRY(c->gc_idx.reserve((size_t)(cap ? cap : 1) * sizeof(int)));
   EFA_TRY(c->gc_wts.reserve((size_t)(cap ? cap : 1) * 16 * sizeof(double)));
   EFA_HIP(launch_gc_fill(ncol, P, c->glat.as<double>(), c->glon.as<double>(), c->ob_lat.as<double>(),
-                         c->ob_lon.as<double>(), c->ob_hw.as<double>(), c->coef.as<double>(), c->gc_off.as<long>(),
-                         c->gc_cnt.as<int>(), c->gc_idx.as<int>(), c->gc_wts.as<double>(), c->gc_order.as<int>(),
+                         c->ob_lon.as<double>(), c->ob_hw.as<double>(), c->coef.as<double>(), c->gc_obtrig.as<double>(),
+                         c->gc_off.as<long>(), c->gc_cnt.as<int>(), c->gc_idx.as<int>(), c->gc_wts.as<double>(), c->gc_order.as<int>(),
                          c->gc_pairs.as<unsigned long long>(), s));
   GcSweepArgs g{};
   g.ncol = ncol;
@@ -697,7 +698,7 @@ int efa_ctx_destroy(efa_ctx* c) {
   if (c->ev_fs) (void)hipEventDestroy(c->ev_fs);
   DevBuf* bufs[] = {&c->ob_pack, &c->out_pack, &c->Ye_rec, &c->coef, &c->ob_val, &c->ob_err, &c->ob_asm, &c->ob_lat, &c->ob_lon, &c->ob_hw,
                     &c->d_prior_mean, &c->d_prior_var, &c->d_post_mean, &c->d_post_var, &c->d_assimilated,
-                    &c->Yw, &c->ymw, &c->traj, &c->tw_mat, &c->status, &c->dbg, &c->W, &c->gc_cnt, &c->gc_ub, &c->gc_order, &c->gc_off, &c->gc_idx, &c->gc_wts, &c->gc_pairs, &c->glat, &c->glon, &c->xm_ws, &c->fs_idx, &c->fs_wts, &c->f_glat, &c->f_glon, &c->f_sl, &c->f_cl, &c->f_valids, &c->f_var, &c->f_time, &c->f_lat, &c->f_lon, &c->f_near, &c->f_idx, &c->f_wts, &c->f_status, &c->h_xm, &c->h_Xp, &c->h_ym, &c->h_Yp};
+                    &c->Yw, &c->ymw, &c->traj, &c->tw_mat, &c->status, &c->dbg, &c->W, &c->gc_cnt, &c->gc_ub, &c->gc_order, &c->gc_obtrig, &c->gc_off, &c->gc_idx, &c->gc_wts, &c->gc_pairs, &c->glat, &c->glon, &c->xm_ws, &c->fs_idx, &c->fs_wts, &c->f_glat, &c->f_glon, &c->f_sl, &c->f_cl, &c->f_valids, &c->f_var, &c->f_time, &c->f_lat, &c->f_lon, &c->f_near, &c->f_idx, &c->f_wts, &c->f_status, &c->h_xm, &c->h_Xp, &c->h_ym, &c->h_Yp};
   for (DevBuf* b : bufs) b->release();
   for (int i = 0; i < 4; ++i)
     if (c->ev[i]) (void)hipEventDestroy(c->ev[i]);

@@ -102,6 +102,29 @@ __global__ __launch_bounds__(kScanThreads) void k_gc_scan(long nblk, const int* 
   if (t == kScanThreads - 1) off[nblk] = part[t];
 }
 
+// Per observation: cos/sin of latitude and longitude and s_lim = sin^2(|halfwidth| / R), the haversine argument at
+// which the taper reaches exactly 0 (distance = 2 halfwidths).  With them the haversine argument of a (column, ob)
+// pair costs ten multiply-adds and no trigonometry: k_gc_build uses that cheap value ONLY to reject pairs that are
+// clearly beyond the cut-off (relative margin 1e-6); every pair it keeps is evaluated with the reference's formula.
+constexpr int kObTrig = 6;  // doubles per ob: cos lat, sin lat, cos lon, sin lon, s_lim, (pad)
+__global__ void k_gc_obtrig(long P, const double* __restrict__ ob_lat, const double* __restrict__ ob_lon,
+                            const double* __restrict__ ob_hw, double* __restrict__ tab) {
+  const long k = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (k >= P) return;
+  const double plat = radians(ob_lat[k]), plon = radians(ob_lon[k]);
+  const double ang = fabs(ob_hw[k]) / kEarthRadiusKm;  // half the cut-off angle
+  double slim = sin(ang);
+  slim = slim * slim;
+  if (!(ang < 1.5)) slim = 4.0;  // cut-off beyond a quarter of the globe (or a NaN radius): nothing is rejected cheaply
+  double* t = tab + k * kObTrig;
+  t[0] = cos(plat);
+  t[1] = sin(plat);
+  t[2] = cos(plon);
+  t[3] = sin(plon);
+  t[4] = slim;
+  t[5] = 0.0;
+}
+
 // order[i] = the block with the i-th longest list (counting sort on cnt >> shift, one workgroup): the sweep
 // hands out blocks longest first, so the last workgroups to start are the cheapest ones.  On a regular
 // lat/lon grid the lists near the poles are several times longer than near the equator, and in blockIdx
@@ -142,7 +165,8 @@ __global__ __launch_bounds__(64 * kBuildWaves) void k_gc_build(long ncol, long n
                                                                const double* __restrict__ ob_lat,
                                                                const double* __restrict__ ob_lon,
                                                                const double* __restrict__ ob_hw,
-                                                               const double* __restrict__ coef, int* __restrict__ cnt,
+                                                               const double* __restrict__ coef,
+                                                               const double* __restrict__ obtrig, int* __restrict__ cnt,
                                                                const long* __restrict__ off, int* __restrict__ idx,
                                                                double* __restrict__ wts,
                                                                unsigned long long* __restrict__ npairs) {
@@ -153,6 +177,7 @@ __global__ __launch_bounds__(64 * kBuildWaves) void k_gc_build(long ncol, long n
   const long col = b * kBlkCols + c;
   const bool col_ok = col < ncol;
   const double la = col_ok ? glat[col] : 0.0, lo = col_ok ? glon[col] : 0.0;
+  const double cg = cos(radians(la)), sg = sin(radians(la)), cl = cos(radians(lo)), sl = sin(radians(lo));
   double la_lo, la_hi;
   block_lat_range(col_ok, la, la_lo, la_hi);
   const long first = off[b];
@@ -171,9 +196,14 @@ __global__ __launch_bounds__(64 * kBuildWaves) void k_gc_build(long ncol, long n
       const long k = k0 + bit;
       double w = 0.0;
       if (bit >= 0 && col_ok) {
-        const double hw = ob_hw[k], olat = ob_lat[k];
-        if (kEarthRadiusKm * fabs(radians(olat - la)) <= 2.0 * fabs(hw) * (1.0 + 1e-9) || !(hw == hw))
+        const double* t = obtrig + k * kObTrig;
+        const double2 tp = *reinterpret_cast<const double2*>(t), tl = *reinterpret_cast<const double2*>(t + 2);
+        const double cc = tp.x * cg;
+        const double h = 0.5 * (1.0 - (cc + tp.y * sg)) + cc * (0.5 * (1.0 - (tl.x * cl + tl.y * sl)));  // sin^2(d / 2R), cheaply
+        if (!(h > t[4] * (1.0 + 1e-6) + 1e-13)) {  // not clearly beyond 2 halfwidths: the reference's own arithmetic decides
+          const double hw = ob_hw[k], olat = ob_lat[k];
           w = gaspari_cohn(distance_to_point_km(la, lo, olat, ob_lon[k]), hw);
+        }
       }
       const unsigned long long bal = __ballot(w != 0.0);
       if (bal == 0ull) continue;  // wave-uniform
@@ -375,12 +405,13 @@ hipError_t launch_gc_bound(long ncol, long P, const double* glat, const double* 
 }
 
 hipError_t launch_gc_fill(long ncol, long P, const double* glat, const double* glon, const double* ob_lat,
-                          const double* ob_lon, const double* ob_hw, const double* coef, const long* off, int* cnt,
-                          int* idx, double* wts, int* order, unsigned long long* npairs, hipStream_t s) {
+                          const double* ob_lon, const double* ob_hw, const double* coef, double* obtrig, const long* off,
+                          int* cnt, int* idx, double* wts, int* order, unsigned long long* npairs, hipStream_t s) {
   const long nblk = gc_num_blocks(ncol);
   if (nblk <= 0) return hipSuccess;
+  hipLaunchKernelGGL(k_gc_obtrig, dim3((unsigned)((P + 255) / 256)), dim3(256), 0, s, P, ob_lat, ob_lon, ob_hw, obtrig);
   hipLaunchKernelGGL(k_gc_build, dim3((unsigned)((nblk + kBuildWaves - 1) / kBuildWaves)), dim3(64 * kBuildWaves), 0, s,
-                     ncol, nblk, P, glat, glon, ob_lat, ob_lon, ob_hw, coef, cnt, off, idx, wts, npairs);
+                     ncol, nblk, P, glat, glon, ob_lat, ob_lon, ob_hw, coef, obtrig, cnt, off, idx, wts, npairs);
   int shift = 0;
   while ((P >> shift) >= kScanThreads) ++shift;
   hipLaunchKernelGGL(k_gc_order, dim3(1), dim3(kScanThreads), 0, s, nblk, cnt, shift, order);

@@ -143,8 +143,9 @@ long gc_num_blocks(long ncol);
 hipError_t launch_gc_bound(long ncol, long P, const double* glat, const double* ob_lat, const double* ob_hw,
                            const double* coef, int* ub, long* off, hipStream_t s);
 hipError_t launch_gc_fill(long ncol, long P, const double* glat, const double* glon, const double* ob_lat,
-                          const double* ob_lon, const double* ob_hw, const double* coef, const long* off, int* cnt,
-                          int* idx, double* wts, int* order, unsigned long long* npairs, hipStream_t s);
+                          const double* ob_lon, const double* ob_hw, const double* coef, double* obtrig /* [P][6] scratch */,
+                          const long* off, int* cnt, int* idx, double* wts, int* order, unsigned long long* npairs,
+                          hipStream_t s);
 hipError_t launch_sweep_gc(const GcSweepArgs& a, hipStream_t s);
 
 struct TransformArgs {
