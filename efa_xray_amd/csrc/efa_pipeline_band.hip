@@ -47,7 +47,7 @@ typedef double v4f64 __attribute__((ext_vector_type(4)));
 constexpr int kVW = 4;        // vector waves (quad per row, one per SIMD)
 constexpr int kGT = 512;      // threads: 4 vector + pivot + 2 G waves + loader
 constexpr int PLg = kPipeLanes;  // lanes per row: same record layout as efa_pipeline.hip
-constexpr int kRingG = 16;    // LDS ring slots for ye rows (two bands)
+constexpr int kRingG = 16;    // LDS ring slots for ye rows (four bands; 8 and 32 slots measure the same)
 constexpr int kPollG = 4;
 constexpr int kRowsWG = kPipeRowsPerWG;  // 64
 #ifndef EFA_BAND

@@ -1,4 +1,8 @@
-"""Diagnostic: per-block times of the band leader (k_pipe_band).  Needs `make -C efa_xray_amd/csrc diag` and
+"""CAUTION (end of round 2): k_pipe_band<13> sits at the edge of the register file -- the product build uses 235 VGPRs
+without spills, the diagnostic build (a few stamps and the dbg pointer more) spills 80 and its FOLLOWERS slow down by 2x, which
+inflates every hand-over figure below.  Check `.vgpr_spill_count` of the diag library (tests/_codeobj.py) before trusting it.
+
+Diagnostic: per-block times of the band leader (k_pipe_band).  Needs `make -C efa_xray_amd/csrc diag` and
 EFA_HIP_LIB=efa_xray_amd/libefa_hip_diag.so.   usage: band_blocktime.py [P] [debug bits] [gram option]"""
 import sys, os, ctypes
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
