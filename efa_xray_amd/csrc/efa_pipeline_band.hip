@@ -97,7 +97,7 @@ __device__ __forceinline__ double rl(double v, int lane) {  // value held by `la
 }
 
 
-template <int NC>
+template <int NC, bool GC = false>
 struct BandShape {
   static constexpr int PAD = 2 * PLg * NC;
   static constexpr int TS = PAD + kTrajScalars;
@@ -105,14 +105,14 @@ struct BandShape {
   static constexpr int SPB = PAD + ((16 - PAD % 32) + 32) % 32;  // band tile row stride == 16 (mod 32): conflict-free B-operand reads
   static constexpr int UREG = (kRowsWG * SP > kRowsWG * (2 * kRowsWG + kScStride + 1)) ? kRowsWG * SP : kRowsWG * (2 * kRowsWG + kScStride + 1);
   static constexpr int kLinv = kNBands * kBand * 16;  // L^-1 of every band, [band][t][16]: A-operand order
-  static constexpr int kYb = 2 * kBand * SPB;         // the band's parked rows, double buffered
+  static constexpr int kYb = GC ? kRowsWG * kRowsWG : 0;  // the block's 64 x 64 corner of the obs-obs taper table (Gaspari-Cohn cycles)
   static size_t lds_doubles() { return (size_t)kRingG * TS + kRowsWG * kRowsWG + UREG + 2 * kRowsWG + kLinv + kYb; }
   static size_t lds_bytes() { return lds_doubles() * sizeof(double) + 32 * sizeof(int); }
 };
 
-template <int NC>
+template <int NC, bool GC>
 __global__ __launch_bounds__(kGT) void k_pipe_band(const PipeArgs a) {
-  using Sh = BandShape<NC>;
+  using Sh = BandShape<NC, GC>;
   constexpr int PAD = Sh::PAD, TS = Sh::TS, SP = Sh::SP, UREG = Sh::UREG;
   constexpr int EPL = (TS + 63) / 64;
   constexpr int NJ = (PAD + 15) / 16;  // accumulator tiles per vector wave in the block's matrix-core layout
@@ -122,8 +122,8 @@ __global__ __launch_bounds__(kGT) void k_pipe_band(const PipeArgs a) {
   double* U = G_s + kRowsWG * kRowsWG;         // union: Yt[64][SP]  then  {g, kb}[64][64], sc[64][8]
   double* pm = U + UREG;                       // [2][64]        parked row means / obs-space means
   double* LinvA = pm + 2 * kRowsWG;            // [8 bands][8][16]  L^-1 of each band: LinvA[b][t][s] = (L^-1)[s][t]
-  double* Yb = LinvA + Sh::kLinv;              // [2][8][SPB]    the band's rows as parked by the vector waves
-  int* ctl = reinterpret_cast<int*>(Yb + Sh::kYb);  // [32]
+  double* tw_s = LinvA + Sh::kLinv;            // [64][64]       GC: taper of the block's obs against the block's rows
+  int* ctl = reinterpret_cast<int*>(tw_s + Sh::kYb);  // [32]
   double* Yt = U;
   double2* s_gk = reinterpret_cast<double2*>(U);  // [step][row] = {G_kj, kb_j}
   double* s_sc = U + 2 * kRowsWG * kRowsWG;       // [ob][4]  rden, beta | innov, active: the four scalars of the ob's record
@@ -327,7 +327,8 @@ __global__ __launch_bounds__(kGT) void k_pipe_band(const PipeArgs a) {
           const bool act = ((asm_mask >> st) & 1) != 0;
           const double xmk = rl(xmv, st);
           const double innov = rl(val_l, st) - xmk;                            // :85
-          const double kc = gk.x * rM1;                                        // :95
+          double kc = gk.x * rM1;                                              // :95
+          if (GC) kc = tw_s[st * kRowsWG + lane] * kc;                         // :115
           const double km = act ? kc * rden : 0.0;                             // :119
           xmv = xmv + km * innov;                                              // :130
           l_xm = (lane == st) ? xmk : l_xm;                                    // this lane's ob: its prior mean (:66)
@@ -397,6 +398,12 @@ __global__ __launch_bounds__(kGT) void k_pipe_band(const PipeArgs a) {
     const double pre_err = (wave == kVW && pre_ob) ? a.ob_error[own0 + lane] : 1.0;
     const bool pre_asm = (wave == kVW && pre_ob) ? (a.ob_assim[own0 + lane] != 0) : false;
     const double pre_sq = sqrt(pre_err);
+    if (GC) {  // the three waves that only wait here fetch the block's corner of the obs-obs taper table (ensrf.py:99-115 on the obs rows)
+      for (int i = (wave - kVW) * 64 + lane; i < kRowsWG * kRowsWG; i += 3 * 64) {
+        const long kg = own0 + (i >> 6), rg = own0 + (i & 63);
+        tw_s[i] = (kg < P && rg < R) ? a.tw[(size_t)kg * R + rg] : 1.0;
+      }
+    }
     __syncthreads();  // B1
     form_gram();
     __syncthreads();  // B2
@@ -426,8 +433,9 @@ __global__ __launch_bounds__(kGT) void k_pipe_band(const PipeArgs a) {
       EFA_PIN_BAND(band);
       double l_rd = 0.0, l_be = 0.0, l_var = 0.0;  // this lane's ob: 1/kdenom, beta, prior variance (latched at its step)
       double gprev[kBand - kEarly], gamprev[kBand - kEarly];  // rows and gammas of the previous band's late steps
+      double kbprev[kBand - kEarly], tprev[kBand - kEarly];   // GC: their gains kb_j and t_j = G_kj - kb_j G_kk
 #pragma unroll
-      for (int o = 0; o < kBand - kEarly; ++o) gprev[o] = gamprev[o] = 0.0;
+      for (int o = 0; o < kBand - kEarly; ++o) gprev[o] = gamprev[o] = kbprev[o] = tprev[o] = 0.0;
       EFA_BLOCKSTAMP(lane == 0, 0);
       EFA_WAIT_OUT(lane == 0, 5, 5, __builtin_amdgcn_s_memrealtime());
       for (int b = 0; b < nbands && ok; ++b) {
@@ -446,7 +454,12 @@ __global__ __launch_bounds__(kGT) void k_pipe_band(const PipeArgs a) {
 #pragma unroll
             for (int s2 = 0; s2 < kBand; ++s2) {
               const double gi = rl(gprev[o], r0 + s2);
-              band[s2] = __builtin_fma(-(gamprev[o] * gi), gprev[o], band[s2]);
+              if (GC) {  // the taper makes the downdate two-term: G_ij -= kb_j G_ki + kb_i t_j
+                band[s2] = __builtin_fma(-gi, kbprev[o], band[s2]);
+                band[s2] = __builtin_fma(-rl(kbprev[o], r0 + s2), tprev[o], band[s2]);
+              } else {
+                band[s2] = __builtin_fma(-(gamprev[o] * gi), gprev[o], band[s2]);
+              }
             }
           }
         }
@@ -455,6 +468,10 @@ __global__ __launch_bounds__(kGT) void k_pipe_band(const PipeArgs a) {
         double linv[kBand];
 #pragma unroll
         for (int s = 0; s < kBand; ++s) linv[s] = (lane == s) ? 1.0 : 0.0;
+        double tw4[kBand];  // GC: taper of the band's obs against this lane's row, fetched once per band
+#pragma unroll
+        for (int s = 0; s < kBand; ++s) tw4[s] = GC ? tw_s[(r0 + (s < s1 ? s : 0)) * kRowsWG + lane] : 1.0;
+        if (GC) EFA_PIN_BAND(tw4);
 #pragma unroll
         for (int s = 0; s < kBand; ++s) {
           if (s < s1) {  // wave-uniform
@@ -477,7 +494,8 @@ __global__ __launch_bounds__(kGT) void k_pipe_band(const PipeArgs a) {
             const double eb = __builtin_fma(-b0, r0c, 1.0);
             const double beta0 = __builtin_fma(r0c, __builtin_fma(eb, eb, eb), r0c);
             const double beta = __builtin_fma(-((beta0 * beta0) * sq0), d, beta0);  // 1 / (1 + sqrt(err / kdenom))  (:135)
-            const double kc = g * rM1;                                    // :95
+            double kc = g * rM1;                                          // :95
+            if (GC) kc = tw4[s] * kc;                                     // :115
             const double km = act ? kc * rden : 0.0;                      // :119
             const double kb = beta * km;                                  // :136
             mu = __builtin_fma(-kb, muk, mu);
@@ -485,11 +503,19 @@ __global__ __launch_bounds__(kGT) void k_pipe_band(const PipeArgs a) {
             // the band's later rows (and L, below) use -- one v_readlane pair per row instead of two
             const double cc = act ? (beta * rden) * rM1 : 0.0;
             const double gam = cc * __builtin_fma(-cc, Gkk, 2.0);
+            const double tj = GC ? __builtin_fma(-kb, Gkk, g) : 0.0;      // t_j = G_kj - kb_j G_kk
 #pragma unroll
             for (int s2 = s + 1; s2 < kBand; ++s2) {
               const double gi = rl(g, r0 + s2);                           // G_k,i of row i = r0 + s2
-              band[s2] = __builtin_fma(-(gam * gi), g, band[s2]);
-              linv[s2] = __builtin_fma(-(cc * gi), linv[s], linv[s2]);    // L[s2][s] = kb_i = c G_k,i
+              if (GC) {  // kb_j = w_kj c G_kj is no longer a multiple of G_kj: the two-term form, kb_i by v_readlane
+                const double kbi = rl(kb, r0 + s2);
+                band[s2] = __builtin_fma(-gi, kb, band[s2]);
+                band[s2] = __builtin_fma(-kbi, tj, band[s2]);
+                linv[s2] = __builtin_fma(-kbi, linv[s], linv[s2]);        // L[s2][s] = kb_i
+              } else {
+                band[s2] = __builtin_fma(-(gam * gi), g, band[s2]);
+                linv[s2] = __builtin_fma(-(cc * gi), linv[s], linv[s2]);  // L[s2][s] = kb_i = c G_k,i
+              }
             }
             const bool mine = lane == kk;
             l_rd = mine ? rden : l_rd;
@@ -500,6 +526,10 @@ __global__ __launch_bounds__(kGT) void k_pipe_band(const PipeArgs a) {
             if (s >= kEarly) {
               gprev[s - kEarly] = g;
               gamprev[s - kEarly] = gam;
+              if (GC) {
+                kbprev[s - kEarly] = kb;
+                tprev[s - kEarly] = tj;
+              }
             }
           }
         }
@@ -781,16 +811,19 @@ __global__ __launch_bounds__(kGT) void k_pipe_band(const PipeArgs a) {
     if (avail > k + kRingG / 2) avail = k + kRingG / 2;  // progress is reported at least every half ring (slot recycling)
     double ya[2 * NC], yb2[2 * NC];
     double2 a01, a23, b01, b23;
-    auto fetch = [&](long kk, double (&y)[2 * NC], double2& s01, double2& s23) {
+    double wa = 1.0, wb = 1.0;  // GC: taper of the record's ob against this row (obs-obs table, fetched with the record)
+    auto fetch = [&](long kk, double (&y)[2 * NC], double2& s01, double2& s23, double& w) {
       const double* slot = ring + (size_t)(kk % kRingG) * TS;
+      if (GC) w = live ? a.tw[(size_t)kk * R + row] : 0.0;
       lds_read_row<PLg, NC>(slot, j, y);
       s01 = *reinterpret_cast<const double2*>(slot + PAD);      // rden, beta
       s23 = *reinterpret_cast<const double2*>(slot + PAD + 2);  // innov, active
     };
-    auto apply = [&](const double (&y)[2 * NC], const double2 s01, const double2 s23) {
+    auto apply = [&](const double (&y)[2 * NC], const double2 s01, const double2 s23, const double w) {
       if (__builtin_amdgcn_readfirstlane((int)(s23.y != 0.0)) != 0) {
         const double dot = group_dot<PLg, NC>(x, y);
-        const double kc = dot * rM1;                        // :95
+        double kc = dot * rM1;                              // :95
+        if (GC) kc = w * kc;                                // :115
         const double km = kc * s01.x;                       // :119
         xm = xm + km * s23.x;                               // :130
         const double kb = s01.y * km;                       // :136
@@ -798,14 +831,14 @@ __global__ __launch_bounds__(kGT) void k_pipe_band(const PipeArgs a) {
         for (int c = 0; c < 2 * NC; ++c) x[c] = __builtin_fma(-kb, y[c], x[c]);  // :141
       }
     };
-    fetch(k, ya, a01, a23);
+    fetch(k, ya, a01, a23, wa);
     while (k < avail) {
-      if (k + 1 < avail) fetch(k + 1, yb2, b01, b23);
-      apply(ya, a01, a23);
+      if (k + 1 < avail) fetch(k + 1, yb2, b01, b23, wb);
+      apply(ya, a01, a23, wa);
       ++k;
       if (k >= avail) break;
-      if (k + 1 < avail) fetch(k + 1, ya, a01, a23);
-      apply(yb2, b01, b23);
+      if (k + 1 < avail) fetch(k + 1, ya, a01, a23, wa);
+      apply(yb2, b01, b23, wb);
       ++k;
     }
     if (lane == 0) g_ctl_set(&ctl[cProg + wave], (int)(k - 1));
@@ -819,20 +852,25 @@ __global__ __launch_bounds__(kGT) void k_pipe_band(const PipeArgs a) {
   }
 }
 
-template <int NC>
-hipError_t band_launch(const PipeArgs& a, hipStream_t s) {
+template <int NC, bool GC>
+hipError_t band_launch_gc(const PipeArgs& a, hipStream_t s) {
   const long grid = (a.R + kRowsWG - 1) / kRowsWG;
-  const size_t lds = BandShape<NC>::lds_bytes();
-  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_pipe_band<NC>),
+  const size_t lds = BandShape<NC, GC>::lds_bytes();
+  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_pipe_band<NC, GC>),
                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   if (e != hipSuccess) return e;
   // every workgroup waits for records of every other: the grid must fit the device at once
   int per_cu = 0;
-  e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reinterpret_cast<const void*>(&k_pipe_band<NC>), kGT, lds);
+  e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reinterpret_cast<const void*>(&k_pipe_band<NC, GC>), kGT, lds);
   if (e != hipSuccess) return e;
   if (grid > (long)per_cu * a.cu_count) return hipErrorCooperativeLaunchTooLarge;
-  hipLaunchKernelGGL((k_pipe_band<NC>), dim3((unsigned)grid), dim3(kGT), lds, s, a);
+  hipLaunchKernelGGL((k_pipe_band<NC, GC>), dim3((unsigned)grid), dim3(kGT), lds, s, a);
   return hipGetLastError();
+}
+
+template <int NC>
+hipError_t band_launch(const PipeArgs& a, hipStream_t s) {
+  return a.loc_mode != 0 ? band_launch_gc<NC, true>(a, s) : band_launch_gc<NC, false>(a, s);
 }
 
 }  // namespace
@@ -840,13 +878,14 @@ hipError_t band_launch(const PipeArgs& a, hipStream_t s) {
 long band_traj_stride(int M) { return 2 * PLg * ((M + 2 * PLg - 1) / (2 * PLg)) + kTrajScalars; }
 
 bool pipeline_band_supported(int M, long R, int loc_mode) {
-  if (loc_mode != 0) return false;  // the rank-one form of the downdate needs kb_j = c G_kj (no taper)
+  if (loc_mode != 0 && loc_mode != 1) return false;
   if (!(M >= 2 && M <= 128 && R > 0 && (R + kRowsWG - 1) / kRowsWG <= kPipeMaxWGs)) return false;
   const int nc = (M + 2 * PLg - 1) / (2 * PLg);
   const int pad = 2 * PLg * nc, ts = pad + kTrajScalars;
-  const int sp = pad + ((2 - pad % 32) + 32) % 32, spb = pad + ((16 - pad % 32) + 32) % 32;
+  const int sp = pad + ((2 - pad % 32) + 32) % 32;
   const size_t ureg = (size_t)kRowsWG * (sp > 2 * kRowsWG + kScStride + 1 ? sp : 2 * kRowsWG + kScStride + 1);
-  const size_t dbl = (size_t)kRingG * ts + kRowsWG * kRowsWG + ureg + 2 * kRowsWG + kNBands * kBand * 16 + 2 * kBand * spb;
+  const size_t dbl = (size_t)kRingG * ts + kRowsWG * kRowsWG + ureg + 2 * kRowsWG + kNBands * kBand * 16 +
+                     (loc_mode != 0 ? (size_t)kRowsWG * kRowsWG : 0);
   return dbl * 8 + 128 <= 160 * 1024;
 }
 

@@ -78,7 +78,7 @@ int efa_ctx_set_stream(efa_ctx *ctx, void *hip_stream);
  *          "path" (EFA_PATH_*), "timing" (0/1), "pipeline" (1: run Phase A as
  *          one persistent launch when it applies, 0: per-batch kernels),
  *          "gram" (how the persistent launch leads a 64-ob block: 2 (default) in Gram space in
- *          bands of 4 obs when the cycle is unlocalised, else as 1; 1 in Gram space step by step;
+ *          bands of 4 obs, with or without localisation; 1 in Gram space step by step;
  *          0 on the vectors; the Gram-space leaders fall back to 0 if their cancellation guard trips),
  *          "spin_limit" (bound of the pipeline's in-kernel polls), "spin_ms" (its wall-time
  *          bound: the persistent launch gives up, and the per-batch kernels take over, when a
