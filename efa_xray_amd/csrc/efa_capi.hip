@@ -323,7 +323,8 @@ int obs_phase(efa_ctx* c, int M, long P, double* ym_dev, double* Yp_dev, const d
     pa.tw = nullptr;
     if (loc_mode == EFA_LOC_GC) {
       EFA_TRY(c->tw_mat.reserve((size_t)P * R * sizeof(double)));
-      EFA_HIP(launch_obs_taper_matrix(P, R, c->ob_lat.as<double>(), c->ob_lon.as<double>(), c->ob_hw.as<double>(),
+      EFA_TRY(c->gc_obtrig.reserve((size_t)P * 6 * sizeof(double)));
+      EFA_HIP(launch_obs_taper_matrix(P, R, c->ob_lat.as<double>(), c->ob_lon.as<double>(), c->ob_hw.as<double>(), c->gc_obtrig.as<double>(),
                                       c->tw_mat.as<double>(), s));
       pa.tw = c->tw_mat.as<double>();
     }

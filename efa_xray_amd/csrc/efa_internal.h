@@ -116,8 +116,8 @@ hipError_t launch_pipeline_band(const PipeArgs& a, hipStream_t s);  // efa_pipel
 bool pipeline_band_supported(int M, long R, int loc_mode);
 long band_traj_stride(int M);  // doubles per trajectory record as k_pipe_band lays them out (its rows are padded to its own lane layout)
 hipError_t launch_fill_u64(unsigned long long* p, size_t n, unsigned long long v, hipStream_t s);
-hipError_t launch_obs_taper_matrix(long P, long R, const double* ob_lat, const double* ob_lon,
-                                   const double* ob_hw, double* tw, hipStream_t s);
+hipError_t launch_obs_taper_matrix(long P, long R, const double* ob_lat, const double* ob_lon, const double* ob_hw,
+                                   double* trig_scratch /* [P][6] */, double* tw, hipStream_t s);
 
 // ---- one-pass localised sweep (efa_gcsweep.hip) ---------------------------------------
 struct GcSweepArgs {

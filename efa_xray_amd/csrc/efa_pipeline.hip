@@ -480,17 +480,50 @@ __global__ void k_fill_u64(u64* p, size_t n, u64 v) {
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) p[i] = v;
 }
 
-// tw[k][row] = GC(haversine(ob_k, ob_row) / halfwidth_k): observation.py:68-83 for every pair
+// per ob: cos/sin of latitude and longitude, and s_lim = sin^2(|halfwidth| / R): the haversine argument at which the
+// taper reaches 0 (see efa_gcsweep.hip: the same trig-free rejection, here for the P x P obs-obs pairs)
+constexpr int kObTrigP = 6;
+__global__ void k_obs_trig(long P, const double* __restrict__ lat, const double* __restrict__ lon,
+                           const double* __restrict__ hw, double* __restrict__ tab) {
+  const long k = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (k >= P) return;
+  const double pl = radians(lat[k]), po = radians(lon[k]);
+  const double ang = fabs(hw[k]) / kEarthRadiusKm;
+  double slim = sin(ang);
+  slim = slim * slim;
+  if (!(ang < 1.5)) slim = 4.0;  // cut-off beyond a quarter of the globe (or a NaN radius): nothing is rejected cheaply
+  double* t = tab + k * kObTrigP;
+  t[0] = cos(pl);
+  t[1] = sin(pl);
+  t[2] = cos(po);
+  t[3] = sin(po);
+  t[4] = slim;
+  t[5] = 0.0;
+}
+
+// tw[k][row] = GC(haversine(ob_k, ob_row) / halfwidth_k): observation.py:68-83 for every pair.  Pairs clearly beyond
+// 2 halfwidths (trig-free haversine argument against s_lim, relative margin 1e-6) are 0 without evaluating anything else;
+// every other pair goes through the reference's formula.
 __global__ __launch_bounds__(256) void k_obs_taper_matrix(long P, long R, const double* __restrict__ lat,
                                                           const double* __restrict__ lon,
-                                                          const double* __restrict__ hw, double* __restrict__ tw) {
-  const size_t total = (size_t)P * R;
-  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
-    const long k = (long)(i / R);
-    const long rr = (long)(i - (size_t)k * R);
-    double w = 1.0;
-    if (rr < P) w = gaspari_cohn(haversine_km(lat[k], lon[k], lat[rr], lon[rr]), hw[k]);
-    tw[i] = w;
+                                                          const double* __restrict__ hw, const double* __restrict__ tab,
+                                                          double* __restrict__ tw) {
+  // one row of the table per blockIdx.y (no 64-bit division per element), columns across the threads
+  for (long k = blockIdx.y; k < P; k += gridDim.y) {
+    const double* tk = tab + k * kObTrigP;
+    const double tk0 = tk[0], tk1 = tk[1], tk2 = tk[2], tk3 = tk[3], lim = tk[4] * (1.0 + 1e-6) + 1e-13;
+    const double latk = lat[k], lonk = lon[k], hwk = hw[k];
+    for (long rr = (long)blockIdx.x * blockDim.x + threadIdx.x; rr < R; rr += (long)gridDim.x * blockDim.x) {
+      double w = 1.0;
+      if (rr < P) {
+        const double* tr = tab + rr * kObTrigP;
+        const double cc = tk0 * tr[0];
+        const double h = 0.5 * (1.0 - (cc + tk1 * tr[1])) + cc * (0.5 * (1.0 - (tk2 * tr[2] + tk3 * tr[3])));
+        w = 0.0;
+        if (!(h > lim)) w = gaspari_cohn(haversine_km(latk, lonk, lat[rr], lon[rr]), hwk);
+      }
+      tw[(size_t)k * R + rr] = w;
+    }
   }
 }
 
@@ -544,11 +577,13 @@ hipError_t launch_fill_u64(unsigned long long* p, size_t n, unsigned long long v
 }
 
 hipError_t launch_obs_taper_matrix(long P, long R, const double* ob_lat, const double* ob_lon, const double* ob_hw,
-                                   double* tw, hipStream_t s) {
+                                   double* trig_scratch, double* tw, hipStream_t s) {
   if (P <= 0 || R <= 0) return hipSuccess;
-  size_t g = ((size_t)P * R + 255) / 256;
-  if (g > 256 * 16) g = 256 * 16;
-  hipLaunchKernelGGL(k_obs_taper_matrix, dim3((unsigned)g), dim3(256), 0, s, P, R, ob_lat, ob_lon, ob_hw, tw);
+  hipLaunchKernelGGL(k_obs_trig, dim3((unsigned)((P + 255) / 256)), dim3(256), 0, s, P, ob_lat, ob_lon, ob_hw, trig_scratch);
+  long gx = (R + 255) / 256;
+  if (gx > 64) gx = 64;
+  const long gy = P < 65535 ? P : 65535;
+  hipLaunchKernelGGL(k_obs_taper_matrix, dim3((unsigned)gx, (unsigned)gy), dim3(256), 0, s, P, R, ob_lat, ob_lon, ob_hw, trig_scratch, tw);
   return hipGetLastError();
 }
 

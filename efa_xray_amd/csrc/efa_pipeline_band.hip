@@ -101,27 +101,28 @@ template <int NC, bool GC = false>
 struct BandShape {
   static constexpr int PAD = 2 * PLg * NC;
   static constexpr int TS = PAD + kTrajScalars;
+  static constexpr int TSR = TS + (GC ? kRowsWG : 0);  // ring slot: the record, then (GC) the taper of its ob against this workgroup's 64 rows
   static constexpr int SP = PAD + ((2 - PAD % 32) + 32) % 32;  // park tile row stride == 2 (mod 32): conflict-free operand reads
   static constexpr int SPB = PAD + ((16 - PAD % 32) + 32) % 32;  // band tile row stride == 16 (mod 32): conflict-free B-operand reads
   static constexpr int UREG = (kRowsWG * SP > kRowsWG * (2 * kRowsWG + kScStride + 1)) ? kRowsWG * SP : kRowsWG * (2 * kRowsWG + kScStride + 1);
-  static constexpr int kLinv = kNBands * kBand * 16;  // L^-1 of every band, [band][t][16]: A-operand order
+  static constexpr int kLinv = kNBands * kBand * kBand;  // L^-1 of every band, [band][t][s]
   static constexpr int kYb = GC ? kRowsWG * kRowsWG : 0;  // the block's 64 x 64 corner of the obs-obs taper table (Gaspari-Cohn cycles)
-  static size_t lds_doubles() { return (size_t)kRingG * TS + kRowsWG * kRowsWG + UREG + 2 * kRowsWG + kLinv + kYb; }
+  static size_t lds_doubles() { return (size_t)kRingG * TSR + kRowsWG * kRowsWG + UREG + 2 * kRowsWG + kLinv + kYb; }
   static size_t lds_bytes() { return lds_doubles() * sizeof(double) + 32 * sizeof(int); }
 };
 
 template <int NC, bool GC>
 __global__ __launch_bounds__(kGT) void k_pipe_band(const PipeArgs a) {
   using Sh = BandShape<NC, GC>;
-  constexpr int PAD = Sh::PAD, TS = Sh::TS, SP = Sh::SP, UREG = Sh::UREG;
+  constexpr int PAD = Sh::PAD, TS = Sh::TS, TSR = Sh::TSR, SP = Sh::SP, UREG = Sh::UREG;
   constexpr int EPL = (TS + 63) / 64;
   constexpr int NJ = (PAD + 15) / 16;  // accumulator tiles per vector wave in the block's matrix-core layout
   extern __shared__ __align__(16) double lds[];
-  double* ring = lds;                          // [kRingG][TS]   ye rows (+ scalars in follower mode)
-  double* G_s = ring + kRingG * TS;            // [64][64]       Gram matrix of the block; later the rows handed to the pivot
+  double* ring = lds;                          // [kRingG][TSR]  ye rows (+ scalars, + GC taper column in follower mode)
+  double* G_s = ring + kRingG * TSR;            // [64][64]       Gram matrix of the block; later the rows handed to the pivot
   double* U = G_s + kRowsWG * kRowsWG;         // union: Yt[64][SP]  then  {g, kb}[64][64], sc[64][8]
   double* pm = U + UREG;                       // [2][64]        parked row means / obs-space means
-  double* LinvA = pm + 2 * kRowsWG;            // [8 bands][8][16]  L^-1 of each band: LinvA[b][t][s] = (L^-1)[s][t]
+  double* LinvA = pm + 2 * kRowsWG;            // [16 bands][4][4]  L^-1 of each band: LinvA[b][t][s] = (L^-1)[s][t]
   double* tw_s = LinvA + Sh::kLinv;            // [64][64]       GC: taper of the block's obs against the block's rows
   int* ctl = reinterpret_cast<int*>(tw_s + Sh::kYb);  // [32]
   double* Yt = U;
@@ -235,9 +236,11 @@ __global__ __launch_bounds__(kGT) void k_pipe_band(const PipeArgs a) {
       while (next < limit && !failed) {
         const int nrec = (int)((limit - next < kPollG) ? (limit - next) : kPollG);
         u64 v[kPollG][EPL];
+        double twv[kPollG];  // GC: taper of each polled ob against this workgroup's row own0 + lane
 #pragma unroll
         for (int d = 0; d < kPollG; ++d) {
           const long kk = next + ((d < nrec) ? d : nrec - 1);
+          twv[d] = (GC && own0 + lane < R) ? a.tw[(size_t)kk * R + own0 + lane] : 0.0;
           const u64* rec = a.traj + (size_t)kk * TS;
 #pragma unroll
           for (int e = 0; e < EPL; ++e) {
@@ -277,12 +280,13 @@ __global__ __launch_bounds__(kGT) void k_pipe_band(const PipeArgs a) {
 #pragma unroll
         for (int d = 0; d < kPollG; ++d) {
           if (d < cnt) {
-            double* slot = ring + (size_t)((next + d) % kRingG) * TS;
+            double* slot = ring + (size_t)((next + d) % kRingG) * TSR;
 #pragma unroll
             for (int e = 0; e < EPL; ++e) {
               const int idx = lane + 64 * e;
               if (idx < TS) slot[idx] = __longlong_as_double((long long)v[d][e]);
             }
+            if (GC) slot[TS + lane] = twv[d];
           }
         }
         next += cnt;
@@ -321,7 +325,7 @@ __global__ __launch_bounds__(kGT) void k_pipe_band(const PipeArgs a) {
         for (int s = 0; s < s1; ++s) {
           const int st = kBand * b + s;
           const long f = own0 + st;
-          const double* slot = ring + (size_t)(f % kRingG) * TS;
+          const double* slot = ring + (size_t)(f % kRingG) * TSR;
           const double2 gk = s_gk[st * kRowsWG + lane];                        // G_kj, kb_j of this lane's row
           const double rden = s_sc[(size_t)st * kScStride];
           const bool act = ((asm_mask >> st) & 1) != 0;
@@ -537,11 +541,9 @@ __global__ __launch_bounds__(kGT) void k_pipe_band(const PipeArgs a) {
         *reinterpret_cast<double2*>(s_sc + (size_t)lane * kScStride) = make_double2(l_rd, l_be);
         s_var[lane] = l_var;
         if (lane < kBand) {
-          double* dst = LinvA + ((size_t)b * kBand + lane) * 16;
+          double* dst = LinvA + ((size_t)b * kBand + lane) * kBand;
 #pragma unroll
           for (int s = 0; s < kBand; ++s) dst[s] = (s < s1) ? linv[s] : 0.0;
-#pragma unroll
-          for (int s = kBand; s < 16; ++s) dst[s] = 0.0;
         }
         if (lane == 0) {
           g_ctl_set(&ctl[cSReady], r0 + s1);
@@ -735,7 +737,7 @@ __global__ __launch_bounds__(kGT) void k_pipe_band(const PipeArgs a) {
               }
               if (bailed) break;
             }
-            const double aop = LinvA[(size_t)b * kBand * 16 + (size_t)lr * 16 + lc];  // A[s = lc][t = lr]
+            const double aop = (lc < kBand) ? LinvA[((size_t)b * kBand + lr) * kBand + lc] : 0.0;  // A[s = lc][t = lr], rows s >= 4 are zero
 #pragma unroll
             for (int J = 0; J < NJ; ++J) {
               const v4f64 z = {0.0, 0.0, 0.0, 0.0};
@@ -745,7 +747,7 @@ __global__ __launch_bounds__(kGT) void k_pipe_band(const PipeArgs a) {
             // D[s = 4 v + lr][col = lc]: register 0 holds ye_{r0 + lr}, which is also B[k = lr][j = lc] of the update
 #pragma unroll
             for (int J = 0; J < NJ; ++J)
-              if (16 * J + lc < PAD) ring[(size_t)((own0 + r0 + lr) % kRingG) * TS + 16 * J + lc] = ye0[J];
+              if (16 * J + lc < PAD) ring[(size_t)((own0 + r0 + lr) % kRingG) * TSR + 16 * J + lc] = ye0[J];
             if (lane == 0) g_ctl_set(&ctl[cYe], 4 * (b + 1));  // the forwarder and the other vector waves may read the band
           } else {
             if (!wait_gt(&ctl[cYe], 4 * (b + 1) - 1, false)) {
@@ -759,7 +761,7 @@ __global__ __launch_bounds__(kGT) void k_pipe_band(const PipeArgs a) {
             const bool valid = lr < s1;
             double av = s_gk[(valid ? st : r0) * kRowsWG + 16 * wave + lc].y;
             av = valid ? -av : 0.0;
-            const double* bs = ring + (size_t)((own0 + (valid ? st : r0)) % kRingG) * TS;
+            const double* bs = ring + (size_t)((own0 + (valid ? st : r0)) % kRingG) * TSR;
 #pragma unroll
             for (int J = 0; J < NJ; ++J) {
               double bv = owner ? ye0[J] : bs[16 * J + lc];
@@ -813,8 +815,8 @@ __global__ __launch_bounds__(kGT) void k_pipe_band(const PipeArgs a) {
     double2 a01, a23, b01, b23;
     double wa = 1.0, wb = 1.0;  // GC: taper of the record's ob against this row (obs-obs table, fetched with the record)
     auto fetch = [&](long kk, double (&y)[2 * NC], double2& s01, double2& s23, double& w) {
-      const double* slot = ring + (size_t)(kk % kRingG) * TS;
-      if (GC) w = live ? a.tw[(size_t)kk * R + row] : 0.0;
+      const double* slot = ring + (size_t)(kk % kRingG) * TSR;
+      if (GC) w = slot[TS + i_loc];  // put there by the loader wave together with the record
       lds_read_row<PLg, NC>(slot, j, y);
       s01 = *reinterpret_cast<const double2*>(slot + PAD);      // rden, beta
       s23 = *reinterpret_cast<const double2*>(slot + PAD + 2);  // innov, active
@@ -884,7 +886,7 @@ bool pipeline_band_supported(int M, long R, int loc_mode) {
   const int pad = 2 * PLg * nc, ts = pad + kTrajScalars;
   const int sp = pad + ((2 - pad % 32) + 32) % 32;
   const size_t ureg = (size_t)kRowsWG * (sp > 2 * kRowsWG + kScStride + 1 ? sp : 2 * kRowsWG + kScStride + 1);
-  const size_t dbl = (size_t)kRingG * ts + kRowsWG * kRowsWG + ureg + 2 * kRowsWG + kNBands * kBand * 16 +
+  const size_t dbl = (size_t)kRingG * (ts + (loc_mode != 0 ? kRowsWG : 0)) + kRowsWG * kRowsWG + ureg + 2 * kRowsWG + kNBands * kBand * kBand +
                      (loc_mode != 0 ? (size_t)kRowsWG * kRowsWG : 0);
   return dbl * 8 + 128 <= 160 * 1024;
 }
