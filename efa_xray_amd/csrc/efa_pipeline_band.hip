@@ -103,11 +103,10 @@ struct BandShape {
   static constexpr int TS = PAD + kTrajScalars;
   static constexpr int TSR = TS + (GC ? kRowsWG : 0);  // ring slot: the record, then (GC) the taper of its ob against this workgroup's 64 rows
   static constexpr int SP = PAD + ((2 - PAD % 32) + 32) % 32;  // park tile row stride == 2 (mod 32): conflict-free operand reads
-  static constexpr int SPB = PAD + ((16 - PAD % 32) + 32) % 32;  // band tile row stride == 16 (mod 32): conflict-free B-operand reads
   static constexpr int UREG = (kRowsWG * SP > kRowsWG * (2 * kRowsWG + kScStride + 1)) ? kRowsWG * SP : kRowsWG * (2 * kRowsWG + kScStride + 1);
   static constexpr int kLinv = kNBands * kBand * kBand;  // L^-1 of every band, [band][t][s]
-  static constexpr int kYb = GC ? kRowsWG * kRowsWG : 0;  // the block's 64 x 64 corner of the obs-obs taper table (Gaspari-Cohn cycles)
-  static size_t lds_doubles() { return (size_t)kRingG * TSR + kRowsWG * kRowsWG + UREG + 2 * kRowsWG + kLinv + kYb; }
+  static constexpr int kTw = GC ? kRowsWG * kRowsWG : 0;  // the block's 64 x 64 corner of the obs-obs taper table (Gaspari-Cohn cycles)
+  static size_t lds_doubles() { return (size_t)kRingG * TSR + kRowsWG * kRowsWG + UREG + 2 * kRowsWG + kLinv + kTw; }
   static size_t lds_bytes() { return lds_doubles() * sizeof(double) + 32 * sizeof(int); }
 };
 
@@ -124,7 +123,7 @@ __global__ __launch_bounds__(kGT) void k_pipe_band(const PipeArgs a) {
   double* pm = U + UREG;                       // [2][64]        parked row means / obs-space means
   double* LinvA = pm + 2 * kRowsWG;            // [16 bands][4][4]  L^-1 of each band: LinvA[b][t][s] = (L^-1)[s][t]
   double* tw_s = LinvA + Sh::kLinv;            // [64][64]       GC: taper of the block's obs against the block's rows
-  int* ctl = reinterpret_cast<int*>(tw_s + Sh::kYb);  // [32]
+  int* ctl = reinterpret_cast<int*>(tw_s + Sh::kTw);  // [32]
   double* Yt = U;
   double2* s_gk = reinterpret_cast<double2*>(U);  // [step][row] = {G_kj, kb_j}
   double* s_sc = U + 2 * kRowsWG * kRowsWG;       // [ob][4]  rden, beta | innov, active: the four scalars of the ob's record
