@@ -292,10 +292,144 @@ hipError_t transform_nu(const TransformArgs& a, hipStream_t s) {
   return a.fused_members ? transform_launch<NU, true, false, false>(a, s) : transform_launch<NU, false, false, false>(a, s);
 }
 
+
+// ---- ensembles of 137 .. 256 members ----------------------------------------------------------------------
+// The LDS image of [T | w] no longer fits one CU (M^2 x 8 B > 160 KB), so the product is cut into column groups of
+// kWideTiles 16-wide tiles: blockIdx.y takes one group, stages only that part of the image and re-reads the
+// rows (2 .. 5 reads of the state instead of 1; still one write, and still ONE pass where the sweep path would
+// make one read+write pass per 64 observations).  Same operand layouts as k_transform; no prefetch (the A
+// operand of 256 members is 128 registers), no narrow last tile.
+constexpr int kWideTiles = 4;
+template <int NU, bool FUSED, bool AL>
+__global__ __launch_bounds__(kThreadsT) void k_transform_wide(const TransformArgs p) {
+  constexpr int NTG = kWideTiles;
+  constexpr int kSteps = 2 * NU;
+  extern __shared__ __align__(16) double Bs[];  // [(u*2+h)*NTG + t][64] for this group's tiles
+  const int M = p.M;
+  const int tid = threadIdx.x;
+  const int t0 = (int)blockIdx.y * NTG;         // first 16-wide tile of this group
+  for (int i = tid; i < kSteps * NTG * 64; i += kThreadsT) {
+    const int l = i & 63, st = i >> 6;
+    const int t = st % NTG, s = st / NTG;
+    const int u = s >> 1, h = s & 1;
+    const int g = l >> 4, n = l & 15;
+    const int m = 8 * u + 2 * g + h;
+    const int j = 16 * (t0 + t) + n;
+    double v = 0.0;
+    if (m < M) {
+      if (j < M) v = FUSED ? p.T[(size_t)m * M + j] + p.w[m] : p.T[(size_t)m * M + j];
+      else if (j == M && !FUSED) v = p.w[m];
+    }
+    Bs[i] = v;
+  }
+  __syncthreads();
+
+  const int lane = tid & 63;
+  const int g = lane >> 4, n = lane & 15;
+  const long ntiles = (p.nrows + 15) / 16;
+  const long nwaves = (long)gridDim.x * (kThreadsT / 64);
+  const int tM = M >> 4, nM = M & 15;  // tile / lane column holding the mean increment (perturbation form)
+  const long last_row = p.nrows - 1;
+  for (long tile = (long)blockIdx.x * (kThreadsT / 64) + (tid >> 6); tile < ntiles; tile += nwaves) {
+    const long r0 = tile * 16;
+    const long r = r0 + n;
+    double a[2 * NU];
+    load_tile<NU, false, AL>(p.Xin, r < last_row ? r : last_row, M, g, a);
+#pragma unroll
+    for (int c = 0; c < 2 * NU; ++c) {  // slots beyond M (only in the last chunk) are zero
+      const int m = 8 * (c >> 1) + 2 * g + (c & 1);
+      if (m >= M) a[c] = 0.0;
+    }
+    double rmean = 0.0;
+    if (FUSED) {
+      double s4[4] = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+      for (int c = 0; c < 2 * NU; ++c) s4[c & 3] += a[c];
+      double sm = (s4[0] + s4[1]) + (s4[2] + s4[3]);
+      sm += __shfl_xor(sm, 16, 64);
+      sm += __shfl_xor(sm, 32, 64);
+      rmean = sm / (double)M;
+#pragma unroll
+      for (int c = 0; c < 2 * NU; ++c) {
+        const int m = 8 * (c >> 1) + 2 * g + (c & 1);
+        a[c] = (m < M) ? a[c] - rmean : 0.0;
+      }
+    }
+    v4f64 acc[NTG];
+#pragma unroll
+    for (int t = 0; t < NTG; ++t) acc[t] = (v4f64){0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+    for (int s = 0; s < kSteps; ++s) {
+#pragma unroll
+      for (int t = 0; t < NTG; ++t) acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[s], Bs[((size_t)s * NTG + t) * 64 + lane], acc[t], 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    double base[4];
+#pragma unroll
+    for (int v = 0; v < 4; ++v) {
+      const long rr = r0 + 4 * v + g;
+      if (FUSED) {
+        base[v] = __shfl(rmean, 4 * v + g, 64);
+      } else {
+        double dm = 0.0;
+#pragma unroll
+        for (int t = 0; t < NTG; ++t)
+          if (t0 + t == tM) dm = __shfl(acc[t][v], (lane & 48) | nM, 64);
+        base[v] = p.xin[rr < last_row ? rr : last_row] + dm;
+      }
+    }
+#pragma unroll
+    for (int t = 0; t < NTG; ++t) {
+      const int col = 16 * (t0 + t) + n;
+#pragma unroll
+      for (int v = 0; v < 4; ++v) {
+        const long row = r0 + 4 * v + g;
+        if (col < M && row < p.nrows) p.Xout[(size_t)row * M + col] = FUSED ? (base[v] + acc[t][v]) : acc[t][v];
+      }
+    }
+    if (!FUSED && n == 0 && tM >= t0 && tM < t0 + NTG) {  // the group that holds column M writes the means
+#pragma unroll
+      for (int v = 0; v < 4; ++v) {
+        const long row = r0 + 4 * v + g;
+        if (row < p.nrows) p.xout[row] = base[v];
+      }
+    }
+  }
+}
+
+template <int NU>
+hipError_t transform_wide_nu(const TransformArgs& a, hipStream_t s) {
+  const size_t lds = (size_t)2 * NU * kWideTiles * 64 * sizeof(double);
+  const bool al = (a.M % 2 == 0) && (reinterpret_cast<uintptr_t>(a.Xin) & 15u) == 0;
+  const int ncols = a.fused_members ? a.M : a.M + 1;
+  const int groups = ((ncols + 15) / 16 + kWideTiles - 1) / kWideTiles;
+  const long ntiles = (a.nrows + 15) / 16;
+  long gx = (ntiles + EFA_T_WAVES - 1) / EFA_T_WAVES;
+  if (gx > 256) gx = 256;
+  if (gx < 1) gx = 1;
+  const dim3 grid((unsigned)gx, (unsigned)groups);
+#define EFA_WIDE_LAUNCH(F, A)                                                                                       \
+  do {                                                                                                              \
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_transform_wide<NU, F, A>),                  \
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                       \
+    if (e != hipSuccess) return e;                                                                                  \
+    hipLaunchKernelGGL((k_transform_wide<NU, F, A>), grid, dim3(kThreadsT), lds, s, a);                              \
+  } while (0)
+  if (a.fused_members) {
+    if (al) EFA_WIDE_LAUNCH(true, true);
+    else EFA_WIDE_LAUNCH(true, false);
+  } else {
+    if (al) EFA_WIDE_LAUNCH(false, true);
+    else EFA_WIDE_LAUNCH(false, false);
+  }
+#undef EFA_WIDE_LAUNCH
+  return hipGetLastError();
+}
+
 }  // namespace
 
-// [T | w] must fit one CU's LDS in MFMA-B order: 2 NU (NU/2 + 1) 64 doubles <= 160 KiB  <=>  M <= 136
-bool transform_supported(int M) { return M >= 2 && M <= 136; }
+// one launch with the whole [T | w] image in LDS up to M = 136; column groups above (k_transform_wide) up to 256
+bool transform_supported(int M) { return M >= 2 && M <= 256; }
 
 hipError_t launch_transform(const TransformArgs& a, hipStream_t s) {
   if (!transform_supported(a.M)) return hipErrorInvalidValue;
@@ -320,6 +454,21 @@ hipError_t launch_transform(const TransformArgs& a, hipStream_t s) {
     case 15: return transform_nu<15>(a, s);
     case 16: return transform_nu<16>(a, s);
     case 17: return transform_nu<17>(a, s);
+    case 18: return transform_wide_nu<18>(a, s);
+    case 19: return transform_wide_nu<19>(a, s);
+    case 20: return transform_wide_nu<20>(a, s);
+    case 21: return transform_wide_nu<21>(a, s);
+    case 22: return transform_wide_nu<22>(a, s);
+    case 23: return transform_wide_nu<23>(a, s);
+    case 24: return transform_wide_nu<24>(a, s);
+    case 25: return transform_wide_nu<25>(a, s);
+    case 26: return transform_wide_nu<26>(a, s);
+    case 27: return transform_wide_nu<27>(a, s);
+    case 28: return transform_wide_nu<28>(a, s);
+    case 29: return transform_wide_nu<29>(a, s);
+    case 30: return transform_wide_nu<30>(a, s);
+    case 31: return transform_wide_nu<31>(a, s);
+    case 32: return transform_wide_nu<32>(a, s);
     default: return hipErrorInvalidValue;
   }
 }

@@ -683,11 +683,12 @@ def test_one_pass_gc_sweep_vs_oracle_ragged_shapes(N, M, P, ncol):
     assert np.array_equal(h_Xap[:N][untouched], Xbp[:N][untouched])
 
 
-@pytest.mark.parametrize("M", [3, 5, 7, 21, 99, 101, 127, 129, 130, 135, 136])
+@pytest.mark.parametrize("M", [3, 5, 7, 21, 99, 101, 127, 129, 130, 135, 136, 137, 160, 201, 255, 256])
 def test_transform_path_for_odd_and_large_ensembles(M):
-    """The one-pass transform serves every M <= 136, odd sizes included (8-byte row alignment: the member pairs are
-    loaded separately), so no ensemble size falls back to one read+write pass per 64 obs; perturbation form through the
-    host ABI and prior members -> posterior members through efa_state_cycle_dev, both against the oracle."""
+    """The one-pass transform serves every M the library accepts (2..256), odd sizes included (8-byte row alignment: the
+    member pairs are loaded separately; above 136 members the [T | w] image is applied in column groups), so no ensemble
+    size falls back to one read+write pass per 64 obs; perturbation form through the host ABI and prior members ->
+    posterior members through efa_state_cycle_dev, both against the oracle."""
     N, P = 1000 + M, 2 * M + 3
     c = _random_case(4000 + M, N, M, P, False, frac_assim=1.0)
     xam, Xap, diag = _run_oracle(c)
