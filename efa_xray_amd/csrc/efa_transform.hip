@@ -141,6 +141,10 @@ __global__ __launch_bounds__(kThreadsT) void k_transform(const TransformArgs p) 
     const long r = tile * 16 + n;
     load_tile<NU, HALF, AL>(p.Xin, r < last_row ? r : last_row, M, g, a);
   }
+  if (kPrefetchT) {  // the first tile has arrived before the loop is entered: its header then needs no vmcnt wait, which on
+#pragma unroll      // the back edge would also wait for the previous tile's stores
+    for (int c = 0; c < 2 * NU; ++c) asm volatile("" : "+v"(a[c]));
+  }
 
   while (tile < ntiles) {
     const long next = tile + nwaves;
@@ -191,6 +195,16 @@ __global__ __launch_bounds__(kThreadsT) void k_transform(const TransformArgs p) 
       __builtin_amdgcn_sched_barrier(0);
     }
 
+    // The next tile's rows are taken over HERE, before this tile's stores are issued: vmcnt counts loads and stores
+    // in one queue on this architecture, so a wait for the prefetched loads placed AFTER the stores (the top of the
+    // next iteration) is also a wait for the stores.  (Measured: the launch time is the same either way -- the stores
+    // drain well within a tile's MFMA phase -- but this is the order that does not depend on it.)
+    if (kPrefetchT) {
+#pragma unroll
+      for (int c = 0; c < 2 * NU; ++c) a[c] = an[c];
+#pragma unroll
+      for (int c = 0; c < 2 * NU; ++c) asm volatile("" : "+v"(a[c]));  // the wait for the loads belongs here
+    }
     // acc[t][v] = D[row 4v+g][col 16t+n]  (layout probed on gfx950: tools/mfma_probe.hip)
     double base[4];  // posterior mean of rows 4v+g: prior mean + column M of the product
 #pragma unroll
@@ -244,10 +258,7 @@ __global__ __launch_bounds__(kThreadsT) void k_transform(const TransformArgs p) 
       }
     }
 
-    if (kPrefetchT) {
-#pragma unroll
-      for (int c = 0; c < 2 * NU; ++c) a[c] = an[c];
-    } else if (next < ntiles) {
+    if (!kPrefetchT && next < ntiles) {
       const long r = next * 16 + n;
       load_tile<NU, HALF, AL>(p.Xin, r < last_row ? r : last_row, M, g, a);
     }
