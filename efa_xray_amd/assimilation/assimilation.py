@@ -14,6 +14,28 @@ import numpy as np
 from efa_xray_amd import _lib
 
 
+def _read_inflation_file(filename):
+    """{variable: (dims, float64 array)} of a netCDF file of inflation factors (assimilation.py:71-79 opens it with
+    xarray.open_dataset).  xarray reads it when importable; otherwise scipy.io.netcdf_file (classic netCDF-3)."""
+    try:
+        import xarray
+    except ImportError:
+        xarray = None
+    out = {}
+    if xarray is not None:
+        with xarray.open_dataset(filename) as ds:
+            for name in ds.data_vars:
+                out[name] = (tuple(ds[name].dims), np.asarray(ds[name].values, dtype=np.float64))
+        return out
+    from scipy.io import netcdf_file
+    with netcdf_file(filename, "r", mmap=False) as f:
+        for name, var in f.variables.items():
+            if name in f.dimensions and len(var.dimensions) == 1:  # a coordinate variable
+                continue
+            out[name] = (tuple(var.dimensions), np.array(var[:], dtype=np.float64))
+    return out
+
+
 class Assimilation(object):
     def __init__(self, state, obs, nproc=1, inflation=None, verbose=False, device=0):
         # assimilation.py:15-33.  The reference also deep-copies the state into
@@ -42,8 +64,10 @@ class Assimilation(object):
         a dict maps variable names to float factors (in place, :103-113) or the dimension names
         'validtime' / 'y' / 'x' to arrays of per-index factors that are broadcast over the other
         dimensions (:82-100; there the reference rebinds `self.prior` to a new object and leaves
-        the caller's alone).  A second call is a no-op (:57-59).  The file form (:71-79, an
-        xarray/netCDF dataset of factors) is not supported: SURVEY.md 8(f4).
+        the caller's alone).  A second call is a no-op (:57-59).  A string names a netCDF file of factors
+        (:71-79): variables of the same names as the state's, on any subset of its dimensions, broadcast by
+        dimension name as xarray does; `self.prior` is rebound.  Read with xarray when importable, otherwise
+        with scipy.io.netcdf_file (classic netCDF-3).
 
         PARITY UNPINNED: the reference's inflation code needs a real xarray Dataset, which the
         build image lacks, so no golden vector covers it; this follows the source text."""
@@ -70,8 +94,31 @@ class Assimilation(object):
             for name in prior.vars():
                 scale_var(name, float(self.inflation))
         elif isinstance(self.inflation, str):
-            raise NotImplementedError("inflation from a file (assimilation.py:71-79) needs an xarray/netCDF dataset "
-                                      "of factors; pass a float or a dict instead")
+            # assimilation.py:71-79: `prior = perts * open_dataset(file) + mean` -- xarray multiplies variables of the
+            # same name and broadcasts by DIMENSION NAME, and rebinds self.prior (the caller's state stays as it was)
+            if self.verbose:
+                print("Trying to load inflation from file: {:s}".format(self.inflation))
+            factors = _read_inflation_file(self.inflation)
+            prior = self.prior = deepcopy(prior)
+            shape = prior._first().shape
+            for name in prior.vars():
+                if name not in factors:
+                    # (xarray's Dataset arithmetic would DROP a variable the file does not hold; it is kept, uninflated)
+                    print("Inflation file holds no factors for variable {:s}.  Left as it is.".format(name))
+                    continue
+                dims, fac = factors[name]
+                view = [1, 1, 1, 1]
+                for d, n in zip(dims, fac.shape):
+                    if d not in self._DIM_AXIS and d != "mem":
+                        raise ValueError("inflation file: dimension %r of %r is not a state dimension" % (d, name))
+                    ax = 3 if d == "mem" else self._DIM_AXIS[d]
+                    if n != shape[ax]:
+                        raise ValueError("inflation file: %r has %d entries along %r, the state has %d" % (name, n, d, shape[ax]))
+                    view[ax] = n
+                order = sorted(range(len(dims)), key=lambda q: 3 if dims[q] == "mem" else self._DIM_AXIS[dims[q]])
+                scale_var(name, np.transpose(fac, order).reshape(view), inplace=False)
+            if self.verbose:
+                print("Succeeded inflation from file: {:s}".format(self.inflation))
         else:
             for k, v in self.inflation.items():  # a dictionary, as in the reference
                 if k in ("validtime", "lat", "lon", "x", "y"):

@@ -298,6 +298,66 @@ class EnsembleState(object):
 
     # -- persistence (ensemble.py:269-273) ---------------------------------------
     def save_to_disk(self, filename="ens_state.nc"):
-        """netCDF via xarray when available (the reference's format);
-        otherwise raises -- on-disk formats are out of scope."""
+        """Dump the state to a netCDF file (ensemble.py:269-273: `self.to_netcdf(filename)`).
+
+        With xarray importable the file is written by xarray, as in the reference.  Without it (the build image)
+        the same content goes out as a classic netCDF-3 file through `scipy.io.netcdf_file` -- which is also the
+        format xarray itself falls back to when netCDF4 is absent: dimensions validtime, y, x, mem; one float64
+        variable per state variable; lat / lon on (y, x) or on their own 1-D dimensions; validtime as stored
+        (datetime64 values as seconds since 1970-01-01 with a `units` attribute).  `EnsembleState.from_netcdf`
+        reads either kind back.  PARITY UNPINNED: the reference's own writer needs xarray."""
+        try:
+            import xarray  # noqa: F401
+        except ImportError:
+            return self._save_netcdf3(filename)
         self.to_xarray().to_netcdf(filename)
+
+    def _save_netcdf3(self, filename):
+        from scipy.io import netcdf_file
+        nt, ny, nx, nm = self._first().shape
+        with netcdf_file(filename, "w", version=2) as f:
+            f.history = "efa_xray_amd EnsembleState.save_to_disk"
+            for d, n in zip(_DIMS, (nt, ny, nx, nm)):
+                f.createDimension(d, n)
+            vt = np.asarray(self.coords.get("validtime", np.arange(nt)))
+            v = f.createVariable("validtime", "d", ("validtime",))
+            if np.issubdtype(vt.dtype, np.datetime64):
+                v[:] = vt.astype("datetime64[s]").astype(np.int64).astype(np.float64)
+                v.units = "seconds since 1970-01-01 00:00:00"
+            else:
+                v[:] = vt.astype(np.float64)
+            for name in ("lat", "lon"):
+                c = np.asarray(self.coords[name], dtype=np.float64)
+                if c.ndim == 2:
+                    f.createVariable(name, "d", ("y", "x"))[:] = c
+                else:  # 1-D coordinates keep a dimension of their own (they need not match y or x)
+                    f.createDimension(name + "_1d", c.shape[0])
+                    f.createVariable(name, "d", (name + "_1d",))[:] = c
+            f.createVariable("mem", "d", ("mem",))[:] = np.asarray(self.coords.get("mem", np.arange(1, nm + 1)), dtype=np.float64)
+            for name, val in self.variables.items():
+                f.createVariable(name, "d", _DIMS)[:] = val
+
+    @classmethod
+    def from_netcdf(cls, filename):
+        """Read a state written by `save_to_disk` (either writer): the counterpart of the reference's
+        `xarray.open_dataset` + `EnsembleState.from_vardict`."""
+        try:
+            import xarray
+        except ImportError:
+            xarray = None
+        if xarray is not None:
+            with xarray.open_dataset(filename) as ds:
+                return cls.from_xarray(ds.load())
+        from scipy.io import netcdf_file
+        with netcdf_file(filename, "r", mmap=False) as f:
+            vd = OrderedDict()
+            cd = {}
+            for name, var in f.variables.items():
+                data = np.array(var[:], dtype=np.float64)
+                if name in _COORD_NAMES:
+                    if name == "validtime" and b"since 1970" in getattr(var, "units", b""):
+                        data = data.astype(np.int64).astype("datetime64[s]")
+                    cd[name] = data
+                elif tuple(var.dimensions) and sorted(var.dimensions) == sorted(_DIMS):
+                    vd[name] = (tuple(var.dimensions), data)
+            return cls.from_vardict(vd, cd)

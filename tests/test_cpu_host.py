@@ -240,8 +240,8 @@ def test_inflate_state_float_dict_forms():
     for i in range(nvar):
         m = arr[i].mean(axis=-1, keepdims=True)
         assert np.allclose(c.prior.variables["v%d" % i], (arr[i] - m) * f[:, None, None, None] + m, rtol=1e-14, atol=1e-14)
-    with pytest.raises(NotImplementedError):
-        Assimilation(mine, [], inflation="factors.nc", verbose=False).inflate_state()
+    with pytest.raises((IOError, OSError)):   # the file form reads a netCDF file of factors: this one does not exist
+        Assimilation(mine, [], inflation="no_such_factors.nc", verbose=False).inflate_state()
 
 
 def test_inflation_hook_runs_inside_format_prior_state_and_update():
@@ -272,3 +272,64 @@ def test_inflation_hook_runs_inside_format_prior_state_and_update():
         with pytest.raises(Stop):
             getattr(none, call)()
         assert none.is_inflated is False and np.array_equal(none.prior.to_vect(), st.to_vect())
+
+
+def _small_state(seed=0, nt=2, ny=3, nx=4, nm=5):
+    from efa_xray_amd import EnsembleState
+    rng = np.random.default_rng(seed)
+    arr = rng.standard_normal((2, nt, ny, nx, nm))
+    lat, lon = np.meshgrid(np.linspace(30, 40, ny), np.linspace(250, 260, nx), indexing="ij")
+    vt = np.array(["2020-01-01T00", "2020-01-01T06"], dtype="datetime64[s]")[:nt]
+    return EnsembleState.from_array(arr, lat, lon, varnames=["t2m", "psfc"], validtime=vt)
+
+
+def test_state_round_trips_through_netcdf(tmp_path):
+    """SURVEY.md 8(f4), ensemble.py:269-273: save_to_disk writes a netCDF file that reads back to the same state
+    (classic netCDF-3 through scipy where xarray is absent).  PARITY UNPINNED: the reference's writer needs xarray."""
+    from efa_xray_amd import EnsembleState
+    st = _small_state()
+    fn = str(tmp_path / "ens_state.nc")
+    st.save_to_disk(fn)
+    back = EnsembleState.from_netcdf(fn)
+    assert back.vars() == st.vars()
+    assert back.shape() == st.shape()
+    for name in st.vars():
+        assert np.array_equal(back.variables[name], st.variables[name])
+    assert np.array_equal(back.coords["lat"], st.coords["lat"]) and np.array_equal(back.coords["lon"], st.coords["lon"])
+    assert np.array_equal(np.asarray(back.coords["validtime"]).astype("datetime64[s]"),
+                          np.asarray(st.coords["validtime"]).astype("datetime64[s]"))
+    assert np.array_equal(back.to_vect(), st.to_vect())
+
+
+def test_inflation_factors_from_a_netcdf_file(tmp_path):
+    """assimilation.py:71-79: `inflation='file.nc'` multiplies the perturbations of each variable by the file's
+    variable of the same name, broadcast by dimension name, and rebinds the prior (the caller's state is untouched).
+    Checked against the closed form; a variable the file does not hold stays as it is."""
+    from scipy.io import netcdf_file
+    from efa_xray_amd.assimilation.assimilation import Assimilation
+    st = _small_state(3)
+    nt, ny, nx = 2, 3, 4
+    rng = np.random.default_rng(5)
+    f_yx = 1.0 + rng.random((ny, nx))
+    fn = str(tmp_path / "inflation.nc")
+    with netcdf_file(fn, "w", version=2) as f:
+        f.createDimension("y", ny)
+        f.createDimension("x", nx)
+        f.createVariable("t2m", "d", ("x", "y"))[:] = f_yx.T          # dimension ORDER in the file is free
+    before = {n: v.copy() for n, v in st.variables.items()}
+    a = Assimilation(st, [], inflation=fn, verbose=False)
+    a.inflate_state()
+    assert a.is_inflated and a.prior is not st
+    for n in st.vars():
+        assert np.array_equal(st.variables[n], before[n])              # the caller's object is not touched
+    m = before["t2m"].mean(axis=-1, keepdims=True)
+    want = (before["t2m"] - m) * f_yx[None, :, :, None] + m
+    assert np.allclose(a.prior.variables["t2m"], want, rtol=1e-15, atol=0)
+    assert np.array_equal(a.prior.variables["psfc"], before["psfc"])   # no factors in the file
+    a.inflate_state()                                                  # second call: no-op (assimilation.py:57-59)
+    assert np.allclose(a.prior.variables["t2m"], want, rtol=1e-15, atol=0)
+    with netcdf_file(fn, "w", version=2) as f:                        # a mismatching file must not broadcast silently
+        f.createDimension("y", ny + 1)
+        f.createVariable("t2m", "d", ("y",))[:] = np.ones(ny + 1)
+    with pytest.raises(ValueError):
+        Assimilation(_small_state(3), [], inflation=fn, verbose=False).inflate_state()

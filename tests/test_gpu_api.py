@@ -94,6 +94,37 @@ def test_update_with_per_variable_and_per_dimension_inflation():
     assert_parity(post_state.to_vect(), ref_post, "post (per-time inflation)")
 
 
+def test_update_with_inflation_factors_from_a_netcdf_file_and_state_round_trip(tmp_path):
+    """f4: `EnSRF(state, obs, inflation='factors.nc').update()` (assimilation.py:71-79: per-variable factors on any
+    subset of the state's dimensions, broadcast by dimension name) == the oracle cycle on the prior inflated in
+    closed form; and the posterior survives `save_to_disk` / `from_netcdf` bit for bit (ensemble.py:269-273).
+    PARITY UNPINNED: the reference's reader and writer need xarray; this follows the source text."""
+    from scipy.io import netcdf_file
+    from efa_xray_amd import EnSRF, EnsembleState
+    state, obs, X, rows, kw = _state_and_obs(6, False, nt=2)
+    nvar, nt, ny, nx, M = state.shape()
+    rng = np.random.default_rng(11)
+    fac = {name: 1.0 + rng.random((ny, nx)) for name in state.vars()}
+    fn = str(tmp_path / "factors.nc")
+    with netcdf_file(fn, "w", version=2) as f:
+        f.createDimension("y", ny)
+        f.createDimension("x", nx)
+        for name in state.vars():
+            f.createVariable(name, "d", ("y", "x"))[:] = fac[name]
+    mine = deepcopy(state)
+    post_state, _ = EnSRF(mine, obs, inflation=fn, verbose=False).update()
+    assert np.array_equal(mine.to_vect(), X), "the file form rebinds the prior and leaves the caller's state alone"
+    arr = X.reshape(nvar, nt, ny, nx, M)
+    m = arr.mean(axis=-1, keepdims=True)
+    F = np.stack([fac[name] for name in state.vars()])[:, None, :, :, None]
+    Xi = ((arr - m) * F + m).reshape(-1, M)
+    ref_post, _, _, _ = _oracle_cycle(Xi, rows, obs, kw)
+    assert_parity(post_state.to_vect(), ref_post, "post (inflation factors from a file)")
+    out = str(tmp_path / "post.nc")
+    post_state.save_to_disk(out)
+    assert np.array_equal(EnsembleState.from_netcdf(out).to_vect(), post_state.to_vect())
+
+
 @pytest.mark.parametrize("loc", [False, "GC"])
 def test_statistics_table_from_kernel_diagnostics(loc):
     """f3: `obs_assimilation_statistics(prior, post, obs, from_diagnostics=True)` after a real `update()` equals
