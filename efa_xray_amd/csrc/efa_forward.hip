@@ -7,9 +7,10 @@
 //                   (ensemble.py:178-200) and the linear time weights as coded (ensemble.py:201-224),
 //                   expanded to a stencil of up to 8 (global state row, weight) entries
 //   k_forward_cols  applies a stencil to a column shard of the state (the all-reduce payload)
-// PARITY UNPINNED: the reference's interpolate needs a real xarray Dataset (absent from the build
-// image), so no reference output exists for it; this follows the source text, and ties in the
-// pseudo-distance (the reference's unstable argsort leaves their order open) go to the lower index.
+// Pinned to the reference since round 3: its nearest_points / interpolate / estimate run verbatim in the
+// build container on a duck-typed state and their outputs are fixtures tests/golden/G9, G10, G11
+// (tests/test_gpu_api.py).  Ties in the pseudo-distance (the reference's unstable argsort leaves their
+// order open) go to the lower index.
 #include "efa_device.h"
 #include "efa_internal.h"
 

@@ -151,8 +151,10 @@ int efa_forward_stencil_dev(efa_ctx *ctx, long rows, long row_offset, int M,
  *   sten_wts [P*8], ob_status [P]: 0 ok, 1 time outside the state's range (the
  *   reference prints a message and returns None), 2 grid index out of range (1-D
  *   lat/lon), 3 bad variable index.  Entries 0-3: the earlier valid time, 4-7: the
- *   later one (or the exact match).  PARITY UNPINNED: interpolate needs a real
- *   xarray Dataset, so no reference output exists; this follows the source text. */
+ *   later one (or the exact match).  Pinned to the reference by fixtures
+ *   tests/golden/G9 (2-D lat/lon), G10 (1-D lat/lon) and G11 (EnSRF.update() end to
+ *   end): its nearest_points / interpolate / estimate run verbatim in the build
+ *   container on a duck-typed state (tests/golden/make_goldens.py). */
 int efa_interp_stencils(efa_ctx *ctx, int nvar, int nt, int ny, int nx,
                         int latlon_1d, long n_grid, const double *grid_lat,
                         const double *grid_lon, const double *valid_times, long P,

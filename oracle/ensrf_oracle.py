@@ -243,8 +243,10 @@ def ensrf_cycle(X, HX, ob_value, ob_error, ob_assim, **kw):
 
 
 # ---------------------------------------------------------------------------
-# forward operator (next-row f1): restated from source text only -- the
-# reference's `interpolate` needs a real xarray Dataset and cannot run here.
+# forward operator (next-row f1).  PINNED since round 3: the reference's own
+# nearest_points / interpolate / Observation.estimate run verbatim in the build
+# container on a duck-typed state (tests/golden/make_goldens.py, fixtures G9
+# (2-D lat/lon), G10 (1-D lat/lon) and G11 (EnSRF.update() end to end)).
 # ---------------------------------------------------------------------------
 def nearest_points(grid_lat, grid_lon, lat, lon, npt=1):
     """Indices of the `npt` nearest grid points in the reference's sin/cos
@@ -256,15 +258,22 @@ def nearest_points(grid_lat, grid_lon, lat, lon, npt=1):
 
 
 def interp_space_weights(grid_lat, grid_lon, lat, lon):
-    """4-point inverse-distance stencil (2-D lat/lon branch) of
-    ensemble.py:178-200.  Returns (iy, ix, weights).  The reference's
-    exact-match branch (`distances < 1 km`, ensemble.py:194-196) raises
-    IndexError as written; the restatement gives that point weight 1.
-    PARITY UNPINNED for this function: no reference output exists for it
-    (needs xarray, absent here)."""
-    iy, ix = nearest_points(grid_lat, grid_lon, lat, lon, npt=4)
-    d = np.array([haversine((grid_lat[y, x], grid_lon[y, x]), (lat, lon))
-                  for y, x in zip(list(iy), list(ix))])
+    """4-point inverse-distance stencil of ensemble.py:178-200, both lat/lon
+    branches.  Returns (iy, ix, weights); for 1-D lat/lon iy = ix = n as in
+    ensemble.py:186-188.  The 2-D branch's exact-match case (`distances < 1 km`,
+    ensemble.py:194-196) raises IndexError in the reference (a 2-D index into
+    a 1-D array); the restatement gives that point weight 1, which is what the
+    same statement does in the 1-D branch, where it works (fixture G10)."""
+    grid_lat = np.asarray(grid_lat)
+    grid_lon = np.asarray(grid_lon)
+    if grid_lat.ndim == 2:
+        iy, ix = nearest_points(grid_lat, grid_lon, lat, lon, npt=4)
+        d = np.array([haversine((grid_lat[y, x], grid_lon[y, x]), (lat, lon))
+                      for y, x in zip(list(iy), list(ix))])
+    else:
+        (n,) = nearest_points(grid_lat, grid_lon, lat, lon, npt=4)
+        iy = ix = n
+        d = haversine((grid_lat[n], grid_lon[n]), (lat, lon))
     w = np.zeros(d.shape)
     if (d < 1.0).sum() > 0:
         w[d.argmin()] = 1
@@ -272,3 +281,40 @@ def interp_space_weights(grid_lat, grid_lon, lat, lon):
         w = 1.0 / d
         w /= w.sum()
     return iy, ix, w
+
+
+def interp_time_weights(valids, time):
+    """Time weights of ensemble.py:203-224 as coded (the weight of the LATER
+    valid time is |t - t_later| / dt: swapped, and kept).  `valids` is a
+    datetime64 array; None outside the range (ensemble.py:207-209)."""
+    time64 = np.datetime64(time)
+    valids = np.asarray(valids)
+    timeweights = np.zeros(valids.shape)
+    if (time64 < valids[0]) or (time64 > valids[-1]):
+        return None
+    lastdex = (valids >= time64).argmax()
+    if valids[lastdex] == time64:
+        timeweights[lastdex] = 1
+    else:
+        diff = (valids[lastdex] - valids[lastdex - 1])
+        totsec = np.abs(diff / np.timedelta64(1, 's'))
+        thisdiff = time64 - valids[lastdex]
+        thissec = np.abs(thisdiff / np.timedelta64(1, 's'))
+        timeweights[lastdex] = float(thissec) / totsec
+        timeweights[lastdex - 1] = 1.0 - (float(thissec) / totsec)
+    return timeweights
+
+
+def interpolate(field, grid_lat, grid_lon, valids, time, lat, lon):
+    """EnsembleState.interpolate (ensemble.py:170-239) on one variable's
+    (nt, ny, nx, nmem) array: gather the four points, weight in time (all nt
+    slots, zeros included, ensemble.py:229-232), then in space
+    (ensemble.py:234-237).  Returns (nmem,) -- the reference's 1-D branch
+    returns the same numbers shaped (1, nmem)."""
+    iy, ix, sw = interp_space_weights(grid_lat, grid_lon, lat, lon)
+    tw = interp_time_weights(valids, time)
+    if tw is None:
+        return None
+    interp = np.asarray(field)[:, iy, ix, :]
+    interp = (tw[:, None, None] * interp).sum(axis=0)
+    return (sw[:, None] * interp).sum(axis=0)

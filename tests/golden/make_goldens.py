@@ -18,8 +18,23 @@ objects; none of their functionality is reached on the path above
 NumPy ufunc of the same name).  The state container is duck-typed: a
 subclass of the reference's EnsembleState overriding the accessors that
 need a real xarray Dataset (shape/nstate/nmems/to_vect/from_vect and
-['lat'|'lon']); Observation.estimate is overridden by a linear operator
-(row pick or 4-point weights) because `interpolate` needs xarray.
+['lat'|'lon']); in G1..G8 Observation.estimate is overridden by a linear
+operator (row pick or 4-point weights).
+
+G9..G11 (round 3) pin the forward operator itself: the reference's
+  efa_xray/state/ensemble.py:152-168           nearest_points
+  efa_xray/state/ensemble.py:170-239           interpolate
+  efa_xray/state/ensemble.py:241-252           haversine
+  efa_xray/observation/observation.py:40-50    Observation.estimate
+run verbatim on `InterpState`, a duck state that additionally offers what those
+lines touch: `self['lat'|'lon'|'validtime']` with `.values`, `.shape` and
+`__getitem__`, and `self.variables[var].values` of shape (nt, ny, nx, nmem).
+The stencil WEIGHTS are read off the reference by interpolating a one-hot
+probe state (member m is 1 at flat (t, y, x) index m, 0 elsewhere): its
+estimate IS the weight vector.  The 2-D branch's "< 1 km" exact-match case
+raises IndexError in the reference (ensemble.py:194-196 writes a 2-D index
+into a 1-D array) and is therefore kept out of G9; the 1-D branch's
+spaceweights are (1, 4), so the same statement works there and G10 holds one.
 
 A fixture is data only: inputs and the reference's outputs.
 """
@@ -285,5 +300,153 @@ def main():
               radii=np.random.default_rng(17).uniform(500, 3000, 200), assim=assim, keep=("xam",))
 
 
+# ---------------------------------------------------------------------------
+# f1: the reference's own forward operator (nearest_points / interpolate / estimate)
+# ---------------------------------------------------------------------------
+class _Field:
+    """What `self[...]` / `self.variables[...]` must offer on the lines cited above."""
+
+    def __init__(self, v):
+        self.values = np.asarray(v)
+        self.shape = self.values.shape
+
+    def __getitem__(self, key):
+        return _Field(self.values[key])
+
+
+class InterpState(DuckState):
+    """DuckState + validtime + named variables, for ensemble.py:152-239."""
+
+    def __init__(self, arr, lat, lon, valids, names):
+        DuckState.__init__(self, arr, lat, lon)
+        self._lat = _Field(np.asarray(lat, dtype=np.float64))
+        self._lon = _Field(np.asarray(lon, dtype=np.float64))
+        self._valid = _Field(np.asarray(valids))
+        self.names = list(names)
+
+    @property
+    def variables(self):
+        return dict((n, _Field(self.arr[i])) for i, n in enumerate(self.names))
+
+    def __getitem__(self, key):
+        return {"lat": self._lat, "lon": self._lon, "validtime": self._valid}[key]
+
+    def __deepcopy__(self, memo):
+        return InterpState(self.arr.copy(), self._lat.values.copy(), self._lon.values.copy(),
+                           self._valid.values.copy(), self.names)
+
+
+def _interp_case(name, shape, lat, lon, valids, rng, P, lat_rng, lon_rng, exact=None):
+    nvar, nt, ny, nx, M = shape
+    names = ["var%d" % i for i in range(nvar)]
+    arr = rng.standard_normal((nvar, nt, ny, nx, 1)) + 2.0 * rng.standard_normal(shape)
+    state = InterpState(arr, lat, lon, valids, names)
+    # one-hot probe: member m <-> flat (t, y, x) index m of ONE variable
+    eye = np.eye(nt * ny * nx).reshape(1, nt, ny, nx, nt * ny * nx)
+    probe = InterpState(eye, lat, lon, valids, ["var0"])
+    span = (valids[-1] - valids[0]) / np.timedelta64(1, "s")
+    ob_var = rng.integers(0, nvar, P)
+    ob_lat = rng.uniform(lat_rng[0], lat_rng[1], P)
+    ob_lon = rng.uniform(lon_rng[0], lon_rng[1], P)
+    # times: every third ob exactly ON a valid time, the rest strictly between
+    ob_time = []
+    for k in range(P):
+        if k % 3 == 0:
+            ob_time.append(valids[k % nt])
+        else:
+            ob_time.append(valids[0] + np.timedelta64(int(rng.uniform(1, span - 1)), "s"))
+    ob_time = np.array(ob_time, dtype="datetime64[s]")
+    if exact is not None:                            # 1-D branch only (see the module docstring)
+        k, n = exact
+        ob_lat[k] = state["lat"].values[n] + 1e-4
+        ob_lon[k] = state["lon"].values[n] - 1e-4
+    near = np.zeros((P, 4, len(np.shape(state["lat"].values))), dtype=np.int64)
+    HX = np.zeros((P, M))
+    W = np.zeros((P, nt * ny * nx))
+    for k in range(P):
+        ob = Observation(value=0.0, obtype=names[ob_var[k]], time=ob_time[k], lat=float(ob_lat[k]),
+                         lon=float(ob_lon[k]), error=1.0)
+        near[k] = np.stack(state.nearest_points(ob.lat, ob.lon, npt=4), axis=-1)
+        HX[k] = np.reshape(ob.estimate(state), (M,))            # the 1-D branch returns (1, M)
+        ob.obtype = "var0"
+        W[k] = np.reshape(ob.estimate(probe), (-1,))
+    # an ob outside the valid times: the reference prints and returns None (ensemble.py:207-209)
+    late = Observation(value=0.0, obtype="var0", time=valids[-1] + np.timedelta64(1, "s"), lat=float(ob_lat[0]),
+                       lon=float(ob_lon[0]))
+    assert late.estimate(state) is None
+    fix = dict(shape=np.array(shape), X=arr, grid_lat=np.asarray(lat, dtype=np.float64),
+               grid_lon=np.asarray(lon, dtype=np.float64), validtime=np.asarray(valids, dtype="datetime64[s]"),
+               var_names=np.array(names), ob_var=ob_var.astype(np.int64), ob_time=ob_time, ob_lat=ob_lat, ob_lon=ob_lon,
+               nearest=near, HX=HX, weights=W)
+    path = os.path.join(OUT, name + ".npz")
+    np.savez_compressed(path, **fix)
+    print("%-4s interpolate: shape=%s P=%d nonzero weights/ob=%s -> %s (%.1f KB)" % (
+        name, shape, P, sorted(set((W != 0).sum(axis=1).tolist())), os.path.basename(path), os.path.getsize(path) / 1024))
+    return state, names
+
+
+def main_f1():
+    t0 = np.datetime64("2020-03-01T00:00:00", "s")
+    # ---- G9: 2-D lat/lon, irregular datetime64 valid times, three variables ----
+    rng = np.random.default_rng(21)
+    valids = t0 + np.array([0, 6 * 3600, 9 * 3600, 18 * 3600]).astype("timedelta64[s]")
+    lat, lon = np.meshgrid(np.linspace(30, 50, 14), np.linspace(230, 262, 18), indexing="ij")
+    _interp_case("G9", (3, 4, 14, 18, 12), lat, lon, valids, rng, 48, (31, 49), (231, 261))
+    # ---- G10: 1-D lat/lon branch (ensemble.py:186-190: y index = x index = n) ----
+    rng = np.random.default_rng(22)
+    valids = t0 + np.array([0, 3600, 7200]).astype("timedelta64[s]")
+    _interp_case("G10", (2, 3, 16, 16, 10), np.linspace(30, 50, 16), np.linspace(230, 262, 16), valids, rng, 36,
+                 (31, 49), (231, 261), exact=(7, 5))
+    # ---- G11: EnSRF.update() end to end with the reference's own estimate (no LinOb) ----
+    rng = np.random.default_rng(23)
+    shape = (2, 3, 10, 12, 16)
+    nvar, nt, ny, nx, M = shape
+    names = ["var%d" % i for i in range(nvar)]
+    valids = t0 + np.array([0, 3600, 10800]).astype("timedelta64[s]")
+    lat, lon = np.meshgrid(np.linspace(25, 55, ny), np.linspace(220, 270, nx), indexing="ij")
+    arr = rng.standard_normal((nvar, nt, ny, nx, 1)) + 3.0 * rng.standard_normal(shape)
+    state = InterpState(arr, lat, lon, valids, names)
+    P = 30
+    ob_var = rng.integers(0, nvar, P)
+    ob_lat = rng.uniform(26, 54, P)
+    ob_lon = rng.uniform(221, 269, P)
+    ob_time = np.array([valids[k % nt] if k % 4 == 0 else valids[0] + np.timedelta64(int(rng.uniform(1, 10799)), "s")
+                        for k in range(P)], dtype="datetime64[s]")
+    errors = rng.uniform(0.4, 1.6, P)
+    radii = rng.uniform(600, 2500, P)
+    assim = rng.random(P) > 0.15
+    values = rng.standard_normal(P) * 2.0
+    obs = [Observation(value=float(values[k]), obtype=names[ob_var[k]], time=ob_time[k], error=float(errors[k]),
+                       lat=float(ob_lat[k]), lon=float(ob_lon[k]), assimilate_this=bool(assim[k]),
+                       localize_radius=float(radii[k])) for k in range(P)]
+    HX = np.array([ob.estimate(state) for ob in obs])
+    flt = EnSRF(state, obs, verbose=False, loc="GC")
+    captured = {}
+    orig = flt.format_posterior_state
+
+    def spy(xam, Xap):
+        captured["xam"] = np.array(xam)
+        return orig(xam, Xap)
+
+    flt.format_posterior_state = spy
+    post_state, obs_out = flt.update()
+    nanf = lambda v: np.nan if v is None else float(v)   # noqa: E731
+    fix = dict(shape=np.array(shape), X=arr, grid_lat=lat, grid_lon=lon, validtime=valids.astype("datetime64[s]"),
+               var_names=np.array(names), ob_var=ob_var.astype(np.int64), ob_time=ob_time, ob_lat=ob_lat, ob_lon=ob_lon,
+               ob_value=values, ob_error=errors, ob_assim=assim, ob_radius=radii, loc=np.array("GC"), HX=HX,
+               xam=captured["xam"], post=post_state.to_vect(),
+               prior_mean=np.array([nanf(o.prior_mean) for o in obs_out]),
+               prior_var=np.array([nanf(o.prior_var) for o in obs_out]),
+               post_mean=np.array([nanf(o.post_mean) for o in obs_out]),
+               post_var=np.array([nanf(o.post_var) for o in obs_out]),
+               assimilated=np.array([bool(o.assimilated) for o in obs_out]))
+    path = os.path.join(OUT, "G11.npz")
+    np.savez_compressed(path, **fix)
+    print("G11  EnSRF.update() with Observation.estimate as shipped: shape=%s P=%d assimilated=%d -> %s (%.1f KB)" % (
+        shape, P, int(fix["assimilated"].sum()), os.path.basename(path), os.path.getsize(path) / 1024))
+
+
 if __name__ == "__main__":
-    main()
+    if "--f1-only" not in sys.argv:
+        main()
+    main_f1()

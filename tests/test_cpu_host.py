@@ -188,6 +188,35 @@ def test_observation_defaults_and_interpolate_stencil():
     assert Observation(obtype="v0", time=1e9, lat=40, lon=240).estimate(st) is None
 
 
+@pytest.mark.parametrize("name", ["G9", "G10"])
+def test_host_interpolation_stencil_matches_the_reference(name):
+    """`EnsembleState.interp_stencil` / `interpolate` / `nearest_points` and `Observation.estimate` against what the
+    reference's own ensemble.py:152-239 / observation.py:40-50 returned on the same state (fixtures G9: 2-D lat/lon,
+    datetime64 valid times; G10: the 1-D lat/lon branch incl. one ob within 1 km of a grid point)."""
+    from conftest import load_golden
+    from efa_xray_amd import EnsembleState, Observation
+    g = load_golden(name)
+    nvar, nt, ny, nx, M = [int(v) for v in g["shape"]]
+    names = [str(n) for n in g["var_names"]]
+    st = EnsembleState.from_array(g["X"], g["grid_lat"], g["grid_lon"], varnames=names, validtime=g["validtime"])
+    for k in range(len(g["ob_lat"])):
+        ob = Observation(obtype=names[g["ob_var"][k]], time=g["ob_time"][k], lat=float(g["ob_lat"][k]),
+                         lon=float(g["ob_lon"][k]))
+        near = st.nearest_points(ob.lat, ob.lon, npt=4)
+        assert np.array_equal(np.stack(near, axis=-1), g["nearest"][k])
+        rows, wts = ob.stencil(st)
+        dense = np.zeros(nvar * nt * ny * nx)
+        np.add.at(dense, rows, wts)
+        iv = int(g["ob_var"][k])
+        per_var = dense.reshape(nvar, -1)
+        assert not per_var[np.arange(nvar) != iv].any()
+        np.testing.assert_allclose(per_var[iv], g["weights"][k], rtol=1e-13, atol=0)
+        np.testing.assert_allclose(ob.estimate(st), g["HX"][k], rtol=1e-12, atol=1e-14)
+    late = Observation(obtype=names[0], time=g["validtime"][-1] + np.timedelta64(1, "s"), lat=float(g["ob_lat"][0]),
+                       lon=float(g["ob_lon"][0]))
+    assert late.estimate(st) is None
+
+
 def test_obs_statistics_table_columns():
     from efa_xray_amd import Observation
     from efa_xray_amd.postprocess.postprocess import obs_assimilation_statistics

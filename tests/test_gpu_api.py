@@ -203,8 +203,8 @@ def _point_obs(state, rng, P, lat_rng, lon_rng):
 @pytest.mark.parametrize("one_d", [False, True])
 def test_device_interpolation_stencils_vs_host_and_oracle(one_d):
     """`efa_interp_stencils` against the host restatement `EnsembleState.interp_stencil` (ensemble.py:152-239) and, for
-    the space weights, against the oracle's `interp_space_weights`.  PARITY UNPINNED on both sides: the reference's
-    interpolate needs a real xarray Dataset, absent from the image; all three follow the source text."""
+    the space weights, against the oracle's `interp_space_weights` (both pinned to the reference by fixtures G9/G10:
+    `test_host_interpolation_stencil_matches_the_reference`, `test_oracle_forward_operator_matches_reference`)."""
     from efa_xray_amd import _lib
     state, lat, lon = _interp_state(31, one_d=one_d)
     rng = np.random.default_rng(32)
@@ -248,6 +248,77 @@ def test_device_interpolation_stencils_vs_host_and_oracle(one_d):
         ctx.forward_interp(ny * nx, lo, hi, nvar * nt, M, Xs, HX)
         acc += HX.download()
     assert_parity(acc, ref, "sharded HX sum")
+
+
+@pytest.mark.parametrize("name", ["G9", "G10"])
+def test_device_forward_operator_matches_the_reference(name):
+    """`efa_interp_stencils` + `efa_forward_interp_dev` against what the reference's own nearest_points / interpolate /
+    Observation.estimate (ensemble.py:152-239, observation.py:40-50) returned on the same state: fixtures G9 (2-D lat/lon,
+    irregular datetime64 valid times, obs on and between them, three variables) and G10 (the 1-D lat/lon branch, one ob
+    within 1 km of a grid point).  Tolerance 1e-10 as everywhere."""
+    from conftest import load_golden
+    from efa_xray_amd import _lib
+    g = load_golden(name)
+    nvar, nt, ny, nx, M = [int(v) for v in g["shape"]]
+    P = len(g["ob_lat"])
+    t0 = g["validtime"][0]
+    vt = (g["validtime"] - t0) / np.timedelta64(1, "s")
+    ot = (g["ob_time"] - t0) / np.timedelta64(1, "s")
+    ctx = _lib.get_context(0)
+    idx, wts, st = ctx.interp_stencils(nvar, nt, ny, nx, g["grid_lat"], g["grid_lon"], vt, g["ob_var"], ot,
+                                       g["ob_lat"], g["ob_lon"])
+    assert not st.any()
+    per = nt * ny * nx
+    for k in range(P):
+        dense = np.zeros(nvar * per)
+        keep = idx[k] >= 0
+        np.add.at(dense, idx[k][keep], wts[k][keep])
+        dense = dense.reshape(nvar, per)
+        iv = int(g["ob_var"][k])
+        assert not dense[np.arange(nvar) != iv].any(), "ob %d: weight on another variable" % k
+        assert_parity(dense[iv], g["weights"][k], "ob %d: stencil weights" % k)
+        # the four points are the reference's four (as a set: the order among them carries no meaning downstream)
+        cols = sorted(set(int(r) % (ny * nx) for r, w in zip(idx[k], wts[k]) if r >= 0))
+        if g["nearest"].shape[-1] == 2:
+            ref_cols = sorted(int(y) * nx + int(x) for y, x in g["nearest"][k])
+        else:
+            ref_cols = sorted(int(n) * nx + int(n) for (n,) in g["nearest"][k])
+        assert set(cols) <= set(ref_cols), "ob %d: stencil columns" % k
+    Xd = ctx.to_device(np.ascontiguousarray(g["X"].reshape(-1, M)))
+    HX = ctx.empty((P, M))
+    ctx.forward_interp(ny * nx, 0, ny * nx, nvar * nt, M, Xd, HX)
+    assert_parity(HX.download(), g["HX"], "HX")
+
+
+def test_update_with_plain_observations_matches_the_reference_end_to_end():
+    """G11: the reference's `EnSRF(state, obs, loc='GC').update()` with `Observation.estimate` as shipped -- forward
+    operator, perturbation formation, localised loop, posterior rebuild -- against this package's `EnSRF.update()`
+    on the same state and obs (the stencils are built and applied on the device)."""
+    from conftest import load_golden
+    from efa_xray_amd import EnsembleState, Observation, EnSRF
+    g = load_golden("G11")
+    names = [str(n) for n in g["var_names"]]
+    state = EnsembleState.from_array(g["X"], g["grid_lat"], g["grid_lon"], varnames=names, validtime=g["validtime"])
+    obs = [Observation(value=float(g["ob_value"][k]), obtype=names[g["ob_var"][k]], time=g["ob_time"][k],
+                       error=float(g["ob_error"][k]), lat=float(g["ob_lat"][k]), lon=float(g["ob_lon"][k]),
+                       assimilate_this=bool(g["ob_assim"][k]), localize_radius=float(g["ob_radius"][k]))
+           for k in range(len(g["ob_value"]))]
+    flt = EnSRF(state, obs, verbose=False, loc="GC")
+    assert flt._default_forward_operator()
+    post_state, obs_out = flt.update()
+    assert obs_out is obs
+    assert_parity(post_state.to_vect(), g["post"], "post")
+    for key in ("prior_mean", "prior_var"):
+        assert_parity([getattr(o, key) for o in obs_out], g[key], key)
+    done = g["assimilated"]
+    assert [bool(o.assimilated) for o in obs_out] == done.tolist()
+    for key in ("post_mean", "post_var"):
+        assert_parity([getattr(o, key) for o, a in zip(obs_out, done) if a], g[key][done], key)
+        assert all(getattr(o, key) is None for o, a in zip(obs_out, done) if not a)
+    m, p = EnSRF(state, obs, verbose=False).compute_ob_priors()
+    rm, rp = orc.compute_ob_priors(g["HX"])
+    assert_parity(m, rm, "ob prior means")
+    assert_parity(p, rp, "ob prior perturbations")
 
 
 def test_update_with_the_default_forward_operator_runs_on_device():

@@ -83,3 +83,47 @@ def test_faithful_cost_mode_same_bits(name):
     assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1])
     for key in a[2]:
         assert np.array_equal(a[2][key], b[2][key], equal_nan=True)
+
+
+# ---------------------------------------------------------------------------
+# f1: forward operator, pinned by the reference's own nearest_points / interpolate /
+# Observation.estimate run verbatim (fixtures G9 2-D lat/lon, G10 1-D lat/lon, G11 end to end)
+# ---------------------------------------------------------------------------
+@pytest.mark.parametrize("name", ["G9", "G10"])
+def test_oracle_forward_operator_matches_reference(name):
+    g = load_golden(name)
+    nvar, nt, ny, nx, M = [int(v) for v in g["shape"]]
+    eye = np.eye(nt * ny * nx).reshape(nt, ny, nx, -1)
+    bit = True
+    for k in range(len(g["ob_lat"])):
+        args = (g["grid_lat"], g["grid_lon"], g["validtime"], g["ob_time"][k], g["ob_lat"][k], g["ob_lon"][k])
+        near = orc.nearest_points(g["grid_lat"], g["grid_lon"], g["ob_lat"][k], g["ob_lon"][k], npt=4)
+        assert np.array_equal(np.stack(near, axis=-1), g["nearest"][k]), "ob %d: nearest four" % k
+        hx = orc.interpolate(g["X"][g["ob_var"][k]], *args)
+        w = orc.interpolate(eye, *args)
+        _close(hx, g["HX"][k], "ob %d: estimate" % k)
+        _close(w, g["weights"][k], "ob %d: stencil weights" % k)
+        bit = bit and np.array_equal(hx, g["HX"][k]) and np.array_equal(w, g["weights"][k])
+    # outside the valid times the reference returns None (ensemble.py:207-209)
+    assert orc.interpolate(g["X"][0], g["grid_lat"], g["grid_lon"], g["validtime"],
+                           g["validtime"][-1] + np.timedelta64(1, "s"), g["ob_lat"][0], g["ob_lon"][0]) is None
+    print("%s forward operator bit-identical to reference: %s" % (name, bit))
+
+
+def test_oracle_cycle_with_the_reference_forward_operator_end_to_end():
+    """G11: EnSRF.update() with plain Observations (ensrf.py:33-151 incl. assimilation.py:36-49 ->
+    observation.py:40-50 -> ensemble.py:170-239)."""
+    g = load_golden("G11")
+    nvar, nt, ny, nx, M = [int(v) for v in g["shape"]]
+    N = nvar * nt * ny * nx
+    HX = np.array([orc.interpolate(g["X"][g["ob_var"][k]], g["grid_lat"], g["grid_lon"], g["validtime"],
+                                   g["ob_time"][k], g["ob_lat"][k], g["ob_lon"][k]) for k in range(len(g["ob_lat"]))])
+    _close(HX, g["HX"], "HX")
+    post, xam, _, diag = orc.ensrf_cycle(g["X"].reshape(N, M), HX, g["ob_value"], g["ob_error"], g["ob_assim"],
+                                         loc="GC", ob_lat=g["ob_lat"], ob_lon=g["ob_lon"], ob_halfwidth=g["ob_radius"],
+                                         grid_lat=g["grid_lat"], grid_lon=g["grid_lon"], state_shape=(nvar, nt, ny, nx))
+    _close(xam, g["xam"], "xam")
+    _close(post, g["post"], "post")
+    for key in ("prior_mean", "prior_var", "post_mean", "post_var"):
+        _close(diag[key], g[key], key)
+    assert np.array_equal(diag["assimilated"], g["assimilated"])
