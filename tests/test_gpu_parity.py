@@ -227,7 +227,7 @@ def _run_oracle(c):
 
 def _run_hip(c, path="auto", batch=32, pipeline=None):
     """pipeline: None library default, 0 per-batch kernels, 1 persistent kernel (vector chain),
-    2 persistent kernel (Gram leader), 3 persistent kernel (band leader; Gram leader when localised)"""
+    2 persistent kernel (Gram leader), 3 persistent kernel (band leader, with and without localisation)"""
     ctx = _ctx()
     ctx.set_option("obs_batch", batch)
     if pipeline is not None:
@@ -261,7 +261,7 @@ def test_seeded_shapes_vs_oracle(N, M, P, loc):
     c = _random_case(100 + N + M + P, N, M, P, loc, ncol=(N // 4 if loc and N % 4 == 0 and N >= 1024 else None))
     xam, Xap, diag = _run_oracle(c)
     for path, pipe in ((("sweep", 1), ("auto", 1), ("sweep", 0), ("sweep", 2), ("auto", 2), ("sweep", 3), ("auto", 3)) if not loc
-                       else (("sweep", 1), ("sweep", 0), ("sweep", 2))):
+                       else (("sweep", 1), ("sweep", 0), ("sweep", 2), ("sweep", 3))):
         h_xam, h_Xap, h_diag = _run_hip(c, path=path, pipeline=pipe)
         assert_parity(h_xam, xam, "xam %s" % path)
         assert_parity(h_Xap, Xap, "Xap %s" % path)
@@ -471,6 +471,88 @@ def test_headline_size_properties():
         ctx.set_option("path", 0)
         post.free()
         X.free()
+
+
+def _headline_obs_sets(M, P):
+    """Two obs sets of the headline's shape: "uncorrelated" -- the bench's construction (row picks of a sigma = 3 field) --
+    and "correlated": every ob sees the same 12 smooth modes plus 5 % noise, so the 64 x 64 Gram blocks are close to
+    rank 12 and each pivot removes a large part of the remaining variance (the downdate's hard case)."""
+    rng = np.random.default_rng(77)
+    sets = {}
+    sets["uncorrelated"] = 3.0 * rng.standard_normal((P, M)) + rng.standard_normal((P, 1))
+    t = np.linspace(0.0, 1.0, P)[:, None]
+    modes = np.concatenate([np.cos(np.pi * j * t) for j in range(12)], axis=1)          # (P, 12), smooth in k
+    sets["correlated"] = modes @ rng.standard_normal((12, M)) + 0.05 * rng.standard_normal((P, M)) + 0.3
+    return sets
+
+
+def test_headline_phase_a_and_transform_vs_oracle():
+    """The headline's Phase A (1e4 obs x 100 members, one persistent launch, band leader) and the [T | w] it hands
+    to the transform, DIRECTLY against the oracle (ensrf.py:50-149 run on the obs block with the M identity rows and
+    2 000 state rows as the "state": then Xap[:M] = T, xam[:M] = w).  Compared: all four diagnostics of every ob, the
+    final obs block, T and w as `k_transform` applies them (unfused form on the identity rows), and the fused
+    prior-members -> posterior-members form on the 2 000 rows.  Two obs sets, see `_headline_obs_sets`; the oracle runs
+    of both (about a minute each) go side by side on two host threads."""
+    from concurrent.futures import ThreadPoolExecutor
+    ctx = _ctx()
+    M, P, R = 100, 10_000, 2_000
+    rng = np.random.default_rng(78)
+    sets = _headline_obs_sets(M, P)
+    Xs = rng.standard_normal((R, 1)) + 3.0 * rng.standard_normal((R, M))
+    Xs[:200] = sets["correlated"][:200] + 0.5 * rng.standard_normal((200, M))       # rows that the obs really constrain
+    xsm = Xs.mean(axis=1)
+    Xsp = Xs - xsm[:, None]
+    val, err, asm = {}, {}, {}
+    for name, HX in sets.items():
+        val[name] = HX.mean(axis=1) + rng.standard_normal(P)
+        err[name] = rng.uniform(0.5, 2.0, P) if name == "correlated" else np.ones(P)
+        asm[name] = np.ones(P, dtype=bool)
+    asm["correlated"][rng.choice(P, 300, replace=False)] = False
+
+    def run_oracle(name):
+        ym0, Yp0 = orc.compute_ob_priors(sets[name])
+        xbm = np.hstack((np.zeros(M), xsm, ym0))
+        Xbp = np.vstack((np.eye(M), Xsp, Yp0))
+        return orc.ensrf_update(xbm, Xbp, M + R, val[name], err[name], asm[name])
+
+    with ThreadPoolExecutor(2) as pool:
+        futs = dict((name, pool.submit(run_oracle, name)) for name in sets)
+        got = {}
+        try:
+            for name, HX in sets.items():
+                ctx.set_option("path", 2)
+                Yp = ctx.to_device(HX)
+                ym = ctx.empty((P,))
+                ctx.form_perts(P, M, Yp, ym, Yp)
+                d = ctx.obs_phase(M, P, ym, Yp, val[name], err[name], asm[name])
+                kind = ctx.get_option("phase_a_kind")
+                # unfused transform on [I ; state perturbations]: rows 0..M-1 come out as T (and w in the mean)
+                xm = ctx.to_device(np.hstack((np.zeros(M), xsm)))
+                Xp = ctx.to_device(np.vstack((np.eye(M), Xsp)))
+                ctx.state_phase(M + R, M, xm, Xp, xm, Xp)
+                assert ctx.last_timing()["path"] == 2
+                # fused form: prior members in, posterior members out
+                Xd = ctx.to_device(Xs)
+                post = ctx.empty((R, M))
+                ctx.state_cycle(R, M, Xd, post)
+                got[name] = (d, kind, Yp.download(), ym.download(), xm.download(), Xp.download(), post.download())
+        finally:
+            ctx.set_option("path", 0)
+        for name in sets:
+            xam, Xap, rd = futs[name].result()
+            d, kind, Yp_f, ym_f, xm_f, Xp_f, post = got[name]
+            print("%s: phase_a_kind %d, prior_var range %.3g..%.3g" % (name, kind, rd["prior_var"].min(), rd["prior_var"].max()))
+            assert kind == 4 or name == "correlated", "the band leader did not serve the bench's obs set"
+            for key in ("prior_mean", "prior_var", "post_mean", "post_var"):
+                assert_parity(d[key], rd[key], "%s %s" % (name, key))
+            assert np.array_equal(d["assimilated"], rd["assimilated"])
+            assert_parity(Yp_f, Xap[M + R:], name + " final obs perturbations")
+            assert_parity(ym_f, xam[M + R:], name + " final obs means")
+            assert_parity(Xp_f[:M], Xap[:M], name + " T")
+            assert_parity(xm_f[:M], xam[:M], name + " w")
+            assert_parity(Xp_f[M:], Xap[M:M + R], name + " state perturbations (transform)")
+            assert_parity(xm_f[M:], xam[M:M + R], name + " state means (transform)")
+            assert_parity(post, orc.format_posterior_state(xam[M:M + R], Xap[M:M + R], R), name + " posterior members (fused)")
 
 
 def test_persistent_phase_a_at_its_residency_limit():
