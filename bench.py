@@ -11,13 +11,17 @@ through the product's multi-GPU class (`efa_xray_amd.distributed.ShardedEnSRF` o
 all-reduce of them), obs-space priors, Phase A over the obs block, and the state sweep
 prior members -> posterior members.
 
-The state is ONE global grid partitioned by (y,x) column into contiguous equal blocks, last
-rank takes the remainder (`column_bounds`; reference precedent ensemble.py:98-106).
-  --scaling weak   (default; the headline): the global state has N x (rows of the workload), every
-                   rank holds the workload's rows; value = P*N / time (every ob is assimilated into
-                   N shards' worth of state).
-  --scaling strong: the global state is the workload's (configs[3]: the 38.5 M-row 3-D state), split
-                   N ways; value = P / time.
+The state is ONE global grid partitioned by (y,x) column into contiguous blocks: equal chunks, last
+rank takes the remainder, without localisation (`column_bounds`; reference precedent
+ensemble.py:98-106); chunks of equal COST under Gaspari-Cohn localisation (`balanced_column_bounds`).
+The HX all-reduce is the library's own RCCL collective (`efa_allreduce_sum_dev`).
+
+Defaults.  N = 1: the headline (BASELINE.json's metric: 1e7 x 100 x 1e4 obs, loc=None).
+           N > 1: STRONG scaling of configs[3]'s one global 3-D state (`--workload cfg4`): value = P / (max over
+           ranks of the cycle time); after the timed region rank 0 alone runs the same global problem unsharded
+           so that the line carries a measured `speedup_vs_one_gpu`.  `--workload headline --scaling strong`
+           gives the headline's strong scaling (Phase A is replicated: Amdahl-bound), `--scaling weak` (loc=None
+           workloads only) the old series in which every rank holds the workload's rows.
 
 Prints ONE JSON line on rank 0 (fields documented in DESIGN.md section 6).
 """
@@ -59,8 +63,12 @@ def parse_args():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--workload", default="headline", choices=sorted(WORKLOADS))
-    ap.add_argument("--scaling", default="weak", choices=["weak", "strong"])
+    ap.add_argument("--workload", default=None, choices=sorted(WORKLOADS),
+                    help="default: headline at --gpus 1, cfg4 (configs[3], one global state) at --gpus > 1")
+    ap.add_argument("--scaling", default=None, choices=["weak", "strong"], help="default: strong (the same thing at N = 1)")
+    ap.add_argument("--no-one-gpu-reference", action="store_true",
+                    help="N > 1: skip the unsharded run of the same workload on rank 0 after the timed region")
+    ap.add_argument("--no-balance", action="store_true", help="GC workloads: equal column chunks instead of equal cost")
     ap.add_argument("--rows", type=int, default=None, help="override the workload's row count (loc=None workloads)")
     ap.add_argument("--obs", type=int, default=None, help="override observation count")
     ap.add_argument("--path", default="auto", choices=["auto", "sweep", "transform"])
@@ -141,6 +149,86 @@ def load_traffic(workload, path_name):
         return None
 
 
+def measure(args, wl, strong, world, rank, eng, dist, torch, seed, balance=True):
+    """One workload on `world` ranks (this process is `rank`): inputs generated on the device, warm-up, then
+    `args.steps` timed cycles between barriers.  Returns the raw numbers of THIS rank plus the shard object."""
+    from efa_xray_amd.distributed import ShardedEnSRF
+    ctx = eng.ctx
+    M, P, loc = wl["M"], wl["P"], wl["loc"]
+    if loc == "GC":
+        if not strong and world > 1:
+            raise SystemExit("--scaling weak is defined for loc=None workloads only (a localised cycle has ONE globe)")
+        n_lead, ny, nx = wl["n_lead"], wl["ny"], wl["nx"]
+        lat2, lon2 = np.meshgrid(np.linspace(-90, 90, ny), np.linspace(0, 360 - 360.0 / nx, nx), indexing="ij")
+        glat, glon = lat2.reshape(-1), lon2.reshape(-1)
+        ncol_g = ny * nx
+    else:
+        n_lead = 1
+        ncol_g = wl["rows"] if strong else wl["rows"] * world
+        glat = glon = lat2 = lon2 = None
+    rows_g = n_lead * ncol_g
+    rng = np.random.default_rng(3000 + seed)
+    pick = rng.choice(rows_g, P, replace=False).astype(np.int64)
+    idx = pick[:, None].copy()
+    wts = np.ones((P, 1))
+    err = np.ones(P)
+    ob = dict(value=None, error=err, assim=np.ones(P, dtype=bool))
+    if loc == "GC":
+        col = pick % ncol_g
+        ob.update(loc="GC", lat=glat[col], lon=glon[col], halfwidth=np.full(P, wl["radius_km"]))
+    if loc == "GC" and balance and world > 1:
+        sh = ShardedEnSRF.balanced(eng, n_lead, ncol_g, M, ob, glat, glon, rank=rank, world_size=world)
+    else:
+        sh = ShardedEnSRF(eng, n_lead, ncol_g, M, rank=rank, world_size=world)
+    rows = sh.rows_local
+    ncol_l = sh.hi - sh.lo
+
+    # synthetic inputs (SURVEY.md 8d), generated on device per shard; keyed by GLOBAL row
+    X = eng.empty((rows, M))
+    post = eng.empty((rows, M))
+    for lead in range(n_lead):   # local rows of one lead are one contiguous run of global rows
+        ctx.fill_synthetic(ncol_l, lead * ncol_g + sh.lo, M, seed, 3.0, X.data_ptr() + lead * ncol_l * M * 8)
+    HX0 = sh.partial_estimates(X, idx, wts)
+    sh.all_reduce_sum(HX0)
+    torch.cuda.synchronize()
+    hx_host = HX0.cpu().numpy()
+    ob["value"] = hx_host.mean(axis=1) + np.random.default_rng(4000 + seed).standard_normal(P) * np.sqrt(err)
+
+    def sync_all():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        sh.update(X, post, idx, wts, ob, glat, glon)
+    sync_all()
+    state_ms = obs_ms = 0.0
+    launches = 0
+    path_taken = 0
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        d = sh.update(X, post, idx, wts, ob, glat, glon)
+        t = ctx.last_timing()
+        state_ms += t["state_ms"]
+        obs_ms += t["obs_ms"]
+        launches += t["state_launches"]
+        path_taken = t["path"]
+    sync_all()
+    elapsed = time.perf_counter() - t0
+    my_elapsed = elapsed
+    if world > 1:
+        tt = torch.tensor([elapsed], dtype=torch.float64, device=eng.device)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+    chk = post[:4096].cpu().numpy()
+    assert np.isfinite(chk).all(), "non-finite posterior"
+    pairs = float(ctx.get_option("gc_active_pairs")) if loc == "GC" else None
+    return dict(sh=sh, X=X, post=post, pick=pick, glat=glat, glon=glon, lat2=lat2, lon2=lon2, n_lead=n_lead, ncol_g=ncol_g,
+                rows_g=rows_g, rows=rows, ncol_l=ncol_l, elapsed=elapsed, my_elapsed=my_elapsed, state_ms=state_ms, obs_ms=obs_ms,
+                launches=launches, path_taken=path_taken, n_active=int(d["assimilated"].sum()), pairs=pairs,
+                kind=ctx.get_option("phase_a_kind"))
+
+
 def main():
     args = parse_args()
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -152,15 +240,19 @@ def main():
                              % (args.gpus, world))
         if args.gpus != 1 or world != 1:
             sys.exit(2)
+    if args.workload is None:
+        args.workload = "headline" if world == 1 else "cfg4"
+    if args.scaling is None:
+        args.scaling = "strong"
 
-    import torch            # plumbing only: device memory, the stream, RCCL, barriers
+    import torch            # plumbing only: device memory, the stream, the rendezvous, barriers
     import torch.distributed as dist
-    from efa_xray_amd import _lib
-    from efa_xray_amd.distributed import ShardedEnSRF, HipEngine
+    from efa_xray_amd.distributed import HipEngine
 
     # EFA_BENCH_REHEARSE=1: every rank on cuda:0 with the gloo backend -- a rehearsal of the N > 1 code path
     # (sharding, the HX all-reduce, barriers, max-over-ranks) on a one-GPU box; its timings mean nothing and the
-    # driver never sets it.  Normal runs: one rank per GPU over RCCL ("nccl").
+    # driver never sets it.  Normal runs: one rank per GPU; torch.distributed ("nccl") carries the barriers and the
+    # communicator id, the HX all-reduce itself is the library's RCCL collective.
     rehearse = os.environ.get("EFA_BENCH_REHEARSE", "0") == "1"
     if rehearse:
         local_rank = 0
@@ -182,19 +274,6 @@ def main():
     M, P, loc = wl["M"], wl["P"], wl["loc"]
     strong = args.scaling == "strong"
 
-    # ---- the global grid and this rank's columns ------------------------------------------------
-    if loc == "GC":
-        n_lead, ny, nx = wl["n_lead"], wl["ny"], wl["nx"]
-        nx_g = nx if strong else nx * world                  # weak: N times as many longitudes on the same globe
-        lat2, lon2 = np.meshgrid(np.linspace(-90, 90, ny), np.linspace(0, 360 - 360.0 / nx_g, nx_g), indexing="ij")
-        glat, glon = lat2.reshape(-1), lon2.reshape(-1)
-        ncol_g = ny * nx_g
-    else:
-        n_lead = 1
-        ncol_g = wl["rows"] if strong else wl["rows"] * world
-        glat = glon = None
-    rows_g = n_lead * ncol_g
-
     eng = HipEngine(local_rank)
     ctx = eng.ctx
     ctx.set_option("path", {"auto": 0, "sweep": 1, "transform": 2}[args.path])
@@ -203,65 +282,42 @@ def main():
     if args.gram is not None:
         ctx.set_option("gram", args.gram)
     ctx.set_option("timing", 1)
-    sh = ShardedEnSRF(eng, n_lead, ncol_g, M, rank=rank, world_size=world)
-    rows = sh.rows_local
-    ncol_l = sh.hi - sh.lo
+    collective = "none (one rank)"
+    if world > 1 and not rehearse:
+        eng.init_comm(rank, world)          # the library's own RCCL communicator (efa_comm_init)
+        collective = "efa_allreduce_sum_dev (RCCL ncclAllReduce sum f64 on the context stream)"
+    elif world > 1:
+        collective = "torch.distributed gloo (rehearsal)"
 
-    # ---- synthetic inputs, generated on device per shard; keyed by GLOBAL row ----
     seed = 1000 + sorted(WORKLOADS).index(args.workload)
-    X = eng.empty((rows, M))
-    post = eng.empty((rows, M))
-    for lead in range(n_lead):   # local rows of one lead are one contiguous run of global rows
-        ctx.fill_synthetic(ncol_l, lead * ncol_g + sh.lo, M, seed, 3.0, X.data_ptr() + lead * ncol_l * M * 8)
-    rng = np.random.default_rng(3000 + seed)
-    pick = rng.choice(rows_g, P, replace=False).astype(np.int64)
-    idx = pick[:, None].copy()
-    wts = np.ones((P, 1))
-    err = np.ones(P)
-    ob = dict(value=None, error=err, assim=np.ones(P, dtype=bool))
-    if loc == "GC":
-        col = pick % ncol_g
-        ob.update(loc="GC", lat=glat[col], lon=glon[col], halfwidth=np.full(P, wl["radius_km"]))
+    r = measure(args, wl, strong, world, rank, eng, dist, torch, seed, balance=not args.no_balance)
+    sh, X, post, pick = r["sh"], r["X"], r["post"], r["pick"]
+    glat, glon, lat2, lon2 = r["glat"], r["glon"], r["lat2"], r["lon2"]
+    n_lead, ncol_g, rows_g, rows, ncol_l = r["n_lead"], r["ncol_g"], r["rows_g"], r["rows"], r["ncol_l"]
+    elapsed, state_ms, obs_ms, launches, path_taken = r["elapsed"], r["state_ms"], r["obs_ms"], r["launches"], r["path_taken"]
+    n_active = r["n_active"]
+    nx_g = wl.get("nx")
 
-    HX0 = sh.partial_estimates(X, idx, wts)
-    sh.all_reduce_sum(HX0)
-    torch.cuda.synchronize()
-    hx_host = HX0.cpu().numpy()
-    ob["value"] = hx_host.mean(axis=1) + np.random.default_rng(4000 + seed).standard_normal(P) * np.sqrt(err)
-
-    def step():
-        return sh.update(X, post, idx, wts, ob, glat, glon)
-
-    def sync_all():
-        if world > 1:
-            dist.barrier()
-        torch.cuda.synchronize()
-
-    for _ in range(args.warmup):
-        step()
-    sync_all()
-    state_ms = obs_ms = 0.0
-    launches = 0
-    path_taken = 0
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        d = step()
-        t = ctx.last_timing()
-        state_ms += t["state_ms"]
-        obs_ms += t["obs_ms"]
-        launches += t["state_launches"]
-        path_taken = t["path"]
-    sync_all()
-    elapsed = time.perf_counter() - t0
+    # per-rank view (imbalance is visible here): rows, (column, ob) pairs, phase times, own wall time
+    mine = dict(rank=rank, columns=[int(sh.lo), int(sh.hi)], rows=int(rows), active_pairs=r["pairs"],
+                obs_phase_ms=obs_ms / args.steps, state_phase_ms=state_ms / args.steps,
+                cycle_ms=1e3 * r["my_elapsed"] / args.steps)
+    per_rank = [mine]
     if world > 1:
-        tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        elapsed = float(tt.item())
-    n_active = int(d["assimilated"].sum())
+        per_rank = [None] * world
+        dist.all_gather_object(per_rank, mine)
 
-    # sanity: the posterior must be finite
-    chk = post[:4096].cpu().numpy()
-    assert np.isfinite(chk).all(), "non-finite posterior"
+    # N > 1: the SAME global problem, unsharded, on rank 0 alone (the other ranks wait at the barrier)
+    one_gpu = None
+    if world > 1 and strong and not args.no_one_gpu_reference and not rehearse:
+        X = post = r = None
+        torch.cuda.empty_cache()
+        if rank == 0:
+            r1 = measure(args, wl, True, 1, 0, eng, dist, torch, seed)
+            one_gpu = dict(ms_per_step=1e3 * r1["elapsed"] / args.steps, value=r1["n_active"] / (r1["elapsed"] / args.steps),
+                           obs_phase_ms=r1["obs_ms"] / args.steps, state_phase_ms=r1["state_ms"] / args.steps)
+            r1 = None
+        dist.barrier()
 
     if rank == 0:
         sec_per_step = elapsed / args.steps
@@ -289,7 +345,7 @@ def main():
             kernel, phys_bytes = "k_sweep", 16.0 * rows * (M + 1)
         phys_gbps = phys_bytes / (avg_launch_ms * 1e-3) / 1e9
         if loc == "GC":
-            pairs = float(ctx.get_option("gc_active_pairs"))            # (column, ob) pairs with taper != 0
+            pairs = per_rank[0]["active_pairs"]                          # (column, ob) pairs with taper != 0, rank 0's shard
             flops_step = 4.0 * M * pairs * n_lead
             bytes_touched = 16.0 * (M + 1) * pairs * n_lead             # SURVEY.md 8d, localised configs
         elif path_name == "transform":
@@ -309,8 +365,11 @@ def main():
             "config": {"workload": wl["desc"], "rows_per_gpu": rows, "rows_global": rows_g, "members": M, "obs": P,
                        "loc": loc or "none", "path": path_name, "obs_batch": ctx.get_option("obs_batch"),
                        "phase_a": {1: "pipeline", 2: "per-batch", 3: "pipeline-gram", 4: "pipeline-band"}.get(kind, "?"),
-                       "sharding": "one global grid split by (y,x) column over the ranks (ShardedEnSRF), obs block "
-                                   "replicated, one all-reduce of HX per cycle, no per-observation communication"},
+                       "sharding": "one global grid split by (y,x) column over the ranks (ShardedEnSRF: %s), obs block "
+                                   "replicated, one all-reduce of HX per cycle, no per-observation communication"
+                                   % ("contiguous chunks of equal Gaspari-Cohn cost" if (loc == "GC" and world > 1 and not args.no_balance)
+                                      else "contiguous equal chunks"),
+                       "collective": collective},
             # whole-cycle rates: algorithmic (effective, counts every ob's nominal pass) and physical
             "GBps_algorithmic": bytes_per_ob * n_active * world / sec_per_step / 1e9,
             "phase_ms": {"obs_phase": obs_step_ms, "state_phase": state_step_ms,
@@ -321,7 +380,7 @@ def main():
             # `effective_GBps` (>> peak when one launch assimilates many obs).
             "roofline": {"bound": "hbm", "kernel": kernel, "achieved": phys_gbps, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": phys_gbps / HBM_PEAK_GBPS, "frac_of_copy_ceiling": phys_gbps / HBM_COPY_GBPS,
-                         "traffic": load_traffic(args.workload, "gc" if loc == "GC" else path_name),
+                         "traffic": load_traffic(args.workload, "gc" if loc == "GC" else path_name) if world == 1 else None,
                          "bytes_per_launch_min": phys_bytes, "avg_launch_ms": avg_launch_ms,
                          "launches_per_step": launches_per_step, "obs_per_launch": obs_per_launch,
                          "effective_GBps": bytes_per_ob * obs_per_launch / (avg_launch_ms * 1e-3) / 1e9,
@@ -340,9 +399,19 @@ def main():
             out["roofline"]["active_column_ob_pairs"] = pairs
             out["roofline"]["bytes_touched"] = bytes_touched
             out["roofline"]["bytes_touched_GBps"] = bytes_touched / (state_step_ms * 1e-3) / 1e9
+        if world > 1:
+            out["per_rank"] = per_rank
+            st = np.array([p["state_phase_ms"] for p in per_rank])
+            out["imbalance"] = {"state_phase_max_over_mean": float(st.max() / st.mean())}
+            if loc == "GC":
+                pr_ = np.array([p["active_pairs"] for p in per_rank], dtype=np.float64)
+                out["imbalance"]["active_pairs_max_over_mean"] = float(pr_.max() / pr_.mean())
+            if one_gpu is not None:
+                out["one_gpu_same_workload"] = one_gpu
+                out["speedup_vs_one_gpu"] = value / one_gpu["value"]
         if world == 1 and not args.no_cpu_baseline:
             if loc == "GC":
-                unit_rows, max_units = n_lead * nx_g, ny
+                unit_rows, max_units = n_lead * nx_g, wl["ny"]
             else:
                 unit_rows, max_units = 1, rows
 

@@ -88,7 +88,17 @@ SIGNATURES = {
                                        ctypes.POINTER(ctypes.c_long), ctypes.POINTER(ctypes.c_int)]),
     "efa_fill_synthetic_dev": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_long, ctypes.c_long, ctypes.c_int,
                                               ctypes.c_uint64, ctypes.c_double, ctypes.c_void_p]),
+    "efa_comm_unique_id": (ctypes.c_int, [c_uint8_p]),
+    "efa_comm_init": (ctypes.c_int, [ctypes.c_void_p, c_uint8_p, ctypes.c_int, ctypes.c_int]),
+    "efa_comm_destroy": (ctypes.c_int, [ctypes.c_void_p]),
+    "efa_allreduce_sum_dev": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_long]),
+    "efa_gc_block_counts": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_long, c_double_p, c_double_p, ctypes.c_long,
+                                           c_double_p, c_double_p, c_double_p, c_uint8_p,
+                                           ctypes.POINTER(ctypes.c_int32), ctypes.POINTER(ctypes.c_int32),
+                                           ctypes.POINTER(ctypes.c_uint64)]),
 }
+
+COMM_ID_BYTES = 128
 
 
 class EfaError(RuntimeError):
@@ -440,6 +450,45 @@ class Context(object):
         _check(self.lib, self.lib.efa_last_timing(self.handle, ctypes.byref(s), ctypes.byref(o),
                                                   ctypes.byref(n), ctypes.byref(p)))
         return dict(state_ms=s.value, obs_ms=o.value, state_launches=n.value, path=p.value)
+
+    # -- multi-GPU: the communicator the context owns (RCCL) -----------------------------------------
+    def comm_unique_id(self):
+        """A fresh RCCL id (bytes) for rank 0 to hand to the other ranks."""
+        buf = np.zeros(COMM_ID_BYTES, dtype=np.uint8)
+        _check(self.lib, self.lib.efa_comm_unique_id(_u8p(buf)))
+        return buf.tobytes()
+
+    def comm_init(self, comm_id, rank, world):
+        buf = np.frombuffer(bytes(comm_id), dtype=np.uint8).copy()
+        assert buf.size == COMM_ID_BYTES
+        _check(self.lib, self.lib.efa_comm_init(self.handle, _u8p(buf), int(rank), int(world)))
+
+    def comm_destroy(self):
+        _check(self.lib, self.lib.efa_comm_destroy(self.handle))
+
+    def allreduce_sum(self, buf, count):
+        """buf[count] (device, float64) <- sum over the ranks, in place, on the context's stream."""
+        _check(self.lib, self.lib.efa_allreduce_sum_dev(self.handle, self._addr(buf), int(count)))
+
+    def gc_block_counts(self, grid_lat, grid_lon, ob_lat, ob_lon, ob_halfwidth, ob_assim):
+        """Per block of 16 (y,x) columns under Gaspari-Cohn localisation: the length of its active list and its
+        (column, ob) pairs with a non-zero weight; and the total of the pairs."""
+        glat = np.ascontiguousarray(grid_lat, dtype=np.float64).reshape(-1)
+        glon = np.ascontiguousarray(grid_lon, dtype=np.float64).reshape(-1)
+        ncol = glat.shape[0]
+        P = len(ob_lat)
+        lat = np.ascontiguousarray(ob_lat, dtype=np.float64).reshape(P)
+        lon = np.ascontiguousarray(ob_lon, dtype=np.float64).reshape(P)
+        hw = np.ascontiguousarray(ob_halfwidth, dtype=np.float64).reshape(P)
+        asm = np.ascontiguousarray(np.asarray(ob_assim).astype(bool), dtype=np.uint8).reshape(P)
+        cnt = np.zeros((ncol + 15) // 16, dtype=np.int32)
+        bp = np.zeros_like(cnt)
+        pairs = ctypes.c_uint64(0)
+        i32p = ctypes.POINTER(ctypes.c_int32)
+        _check(self.lib, self.lib.efa_gc_block_counts(self.handle, ncol, _dp(glat), _dp(glon), P, _dp(lat), _dp(lon), _dp(hw),
+                                                      _u8p(asm), cnt.ctypes.data_as(i32p), bp.ctypes.data_as(i32p),
+                                                      ctypes.byref(pairs)))
+        return cnt, bp, int(pairs.value)
 
     def fill_synthetic(self, rows, row_offset, M, seed, sigma, X):
         _check(self.lib, self.lib.efa_fill_synthetic_dev(self.handle, rows, row_offset, M, int(seed),

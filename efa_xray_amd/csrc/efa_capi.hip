@@ -3,6 +3,9 @@
 #include "../../include/efa_hip.h"
 
 #include <hip/hip_runtime.h>
+#include <rccl/rccl.h>  // types and enums only: librccl is opened with dlopen when a communicator is asked for
+
+#include <dlfcn.h>
 
 #include <cstdarg>
 #include <cstdio>
@@ -157,6 +160,10 @@ struct efa_ctx {
   long f_P = 0;       // observations of the stencil held in f_idx / f_wts (0: none)
   // --- host-memory API buffers ----------------------------------------------
   DevBuf h_xm, h_Xp, h_ym, h_Yp;
+  // --- multi-GPU exchange step: an RCCL communicator owned by the context (efa_comm_init) -------------
+  ncclComm_t comm = nullptr;
+  int comm_rank = 0, comm_world = 1;
+  DevBuf gcc_lat, gcc_lon, gcc_oblat, gcc_oblon, gcc_obhw, gcc_coef, gcc_trig, gcc_cnt, gcc_pairs;  // efa_gc_block_counts
   // --- timing -----------------------------------------------------------------
   hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
   double state_ms = 0.0, obs_ms = 0.0;
@@ -632,6 +639,48 @@ int state_phase(efa_ctx* c, long rows, int M, const double* xm_in, const double*
 }  // namespace
 
 // ===========================================================================
+// ---- RCCL, bound at run time: a single-GPU caller never loads it ---------------------------------------
+namespace {
+struct RcclApi {
+  void* lib = nullptr;
+  ncclResult_t (*GetUniqueId)(ncclUniqueId*) = nullptr;
+  ncclResult_t (*CommInitRank)(ncclComm_t*, int, ncclUniqueId, int) = nullptr;
+  ncclResult_t (*AllReduce)(const void*, void*, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
+  ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+  const char* (*GetErrorString)(ncclResult_t) = nullptr;
+};
+RcclApi g_rccl;
+
+int rccl_load() {
+  if (g_rccl.lib) return EFA_OK;
+  const char* names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
+  void* h = nullptr;
+  for (const char* n : names) {
+    h = dlopen(n, RTLD_NOW | RTLD_GLOBAL);
+    if (h) break;
+  }
+  if (!h) return fail(EFA_ERR_UNSUPPORTED, "librccl could not be opened: %s", dlerror());
+  RcclApi a;
+  a.lib = h;
+  a.GetUniqueId = reinterpret_cast<decltype(a.GetUniqueId)>(dlsym(h, "ncclGetUniqueId"));
+  a.CommInitRank = reinterpret_cast<decltype(a.CommInitRank)>(dlsym(h, "ncclCommInitRank"));
+  a.AllReduce = reinterpret_cast<decltype(a.AllReduce)>(dlsym(h, "ncclAllReduce"));
+  a.CommDestroy = reinterpret_cast<decltype(a.CommDestroy)>(dlsym(h, "ncclCommDestroy"));
+  a.GetErrorString = reinterpret_cast<decltype(a.GetErrorString)>(dlsym(h, "ncclGetErrorString"));
+  if (!a.GetUniqueId || !a.CommInitRank || !a.AllReduce || !a.CommDestroy || !a.GetErrorString) {
+    dlclose(h);
+    return fail(EFA_ERR_UNSUPPORTED, "librccl lacks an expected symbol");
+  }
+  g_rccl = a;
+  return EFA_OK;
+}
+#define EFA_RCCL(expr)                                                                                       \
+  do {                                                                                                       \
+    ncclResult_t _r = (expr);                                                                                \
+    if (_r != ncclSuccess) return fail(EFA_ERR_HIP, "%s failed: %s", #expr, g_rccl.GetErrorString(_r));      \
+  } while (0)
+}  // namespace
+
 extern "C" {
 
 int efa_abi_version(void) { return EFA_ABI_VERSION; }
@@ -693,13 +742,16 @@ int efa_ctx_destroy(efa_ctx* c) {
   if (!c) return EFA_OK;
   (void)hipSetDevice(c->device);
   if (c->stream) (void)hipStreamSynchronize(c->stream);
+  if (c->comm && g_rccl.CommDestroy) (void)g_rccl.CommDestroy(c->comm);
+  c->comm = nullptr;
   c->pin_in.release();
   c->pin_out.release();
   c->pin_fs.release();
   if (c->ev_fs) (void)hipEventDestroy(c->ev_fs);
   DevBuf* bufs[] = {&c->ob_pack, &c->out_pack, &c->Ye_rec, &c->coef, &c->ob_val, &c->ob_err, &c->ob_asm, &c->ob_lat, &c->ob_lon, &c->ob_hw,
                     &c->d_prior_mean, &c->d_prior_var, &c->d_post_mean, &c->d_post_var, &c->d_assimilated,
-                    &c->Yw, &c->ymw, &c->traj, &c->tw_mat, &c->status, &c->dbg, &c->W, &c->gc_cnt, &c->gc_ub, &c->gc_order, &c->gc_obtrig, &c->gc_off, &c->gc_idx, &c->gc_wts, &c->gc_pairs, &c->glat, &c->glon, &c->xm_ws, &c->fs_idx, &c->fs_wts, &c->f_glat, &c->f_glon, &c->f_sl, &c->f_cl, &c->f_valids, &c->f_var, &c->f_time, &c->f_lat, &c->f_lon, &c->f_near, &c->f_idx, &c->f_wts, &c->f_status, &c->h_xm, &c->h_Xp, &c->h_ym, &c->h_Yp};
+                    &c->Yw, &c->ymw, &c->traj, &c->tw_mat, &c->status, &c->dbg, &c->W, &c->gc_cnt, &c->gc_ub, &c->gc_order, &c->gc_obtrig, &c->gc_off, &c->gc_idx, &c->gc_wts, &c->gc_pairs, &c->glat, &c->glon, &c->xm_ws, &c->fs_idx, &c->fs_wts, &c->f_glat, &c->f_glon, &c->f_sl, &c->f_cl, &c->f_valids, &c->f_var, &c->f_time, &c->f_lat, &c->f_lon, &c->f_near, &c->f_idx, &c->f_wts, &c->f_status, &c->h_xm, &c->h_Xp, &c->h_ym, &c->h_Yp,
+                    &c->gcc_lat, &c->gcc_lon, &c->gcc_oblat, &c->gcc_oblon, &c->gcc_obhw, &c->gcc_coef, &c->gcc_trig, &c->gcc_cnt, &c->gcc_pairs};
   for (DevBuf* b : bufs) b->release();
   for (int i = 0; i < 4; ++i)
     if (c->ev[i]) (void)hipEventDestroy(c->ev[i]);
@@ -1082,6 +1134,96 @@ int efa_fill_synthetic_dev(efa_ctx* c, long rows, long row_offset, int M, uint64
   if (rows < 0 || M < 1) return fail(EFA_ERR_INVALID, "bad shape");
   if (rows && !X_dev) return fail(EFA_ERR_INVALID, "null pointer");
   EFA_HIP(efa::launch_fill_synthetic(rows, row_offset, M, seed, sigma, X_dev, c->stream));
+  return EFA_OK;
+}
+
+// ---- the one exchange step, owned by the library ------------------------------------------
+int efa_comm_unique_id(uint8_t* id_out) {
+  if (!id_out) return fail(EFA_ERR_INVALID, "null id");
+  EFA_TRY(rccl_load());
+  static_assert(sizeof(ncclUniqueId) == EFA_COMM_ID_BYTES, "EFA_COMM_ID_BYTES must be sizeof(ncclUniqueId)");
+  ncclUniqueId id;
+  EFA_RCCL(g_rccl.GetUniqueId(&id));
+  std::memcpy(id_out, &id, sizeof(id));
+  return EFA_OK;
+}
+
+int efa_comm_init(efa_ctx* c, const uint8_t* id, int rank, int world) {
+  EFA_TRY(use(c));
+  if (!id || world < 1 || rank < 0 || rank >= world) return fail(EFA_ERR_INVALID, "bad communicator arguments (rank %d of %d)", rank, world);
+  if (c->comm) return fail(EFA_ERR_INVALID, "the context already owns a communicator (efa_comm_destroy first)");
+  EFA_TRY(rccl_load());
+  ncclUniqueId uid;
+  std::memcpy(&uid, id, sizeof(uid));
+  EFA_RCCL(g_rccl.CommInitRank(&c->comm, world, uid, rank));
+  c->comm_rank = rank;
+  c->comm_world = world;
+  return EFA_OK;
+}
+
+int efa_comm_destroy(efa_ctx* c) {
+  EFA_TRY(use(c));
+  if (!c->comm) return EFA_OK;
+  EFA_HIP(hipStreamSynchronize(c->stream));
+  EFA_RCCL(g_rccl.CommDestroy(c->comm));
+  c->comm = nullptr;
+  c->comm_rank = 0;
+  c->comm_world = 1;
+  return EFA_OK;
+}
+
+int efa_allreduce_sum_dev(efa_ctx* c, double* buf_dev, long count) {
+  EFA_TRY(use(c));
+  if (count < 0 || (count && !buf_dev)) return fail(EFA_ERR_INVALID, "bad buffer");
+  if (!c->comm) return fail(EFA_ERR_INVALID, "no communicator: call efa_comm_init first");
+  if (count == 0) return EFA_OK;
+  EFA_RCCL(g_rccl.AllReduce(buf_dev, buf_dev, (size_t)count, ncclDouble, ncclSum, c->comm, c->stream));
+  return EFA_OK;
+}
+
+// ---- cost of a column block under Gaspari-Cohn localisation (the sharding plan of SURVEY.md 8e) ------------
+int efa_gc_block_counts(efa_ctx* c, long ncol, const double* grid_lat, const double* grid_lon, long P, const double* ob_lat,
+                        const double* ob_lon, const double* ob_halfwidth_km, const uint8_t* ob_assim, int32_t* block_count,
+                        int32_t* block_pairs, uint64_t* active_pairs) {
+  EFA_TRY(use(c));
+  if (ncol <= 0 || P < 0) return fail(EFA_ERR_INVALID, "bad shape");
+  if (!grid_lat || !grid_lon || !block_count || (P && (!ob_lat || !ob_lon || !ob_halfwidth_km || !ob_assim)))
+    return fail(EFA_ERR_INVALID, "null pointer");
+  const long nblk = efa::gc_num_blocks(ncol);
+  hipStream_t s = c->stream;
+  std::vector<double> coef((size_t)(P ? P : 1) * efa::kCoefStride, 0.0), hw((size_t)(P ? P : 1), 1.0);
+  for (long k = 0; k < P; ++k) {
+    const bool on = ob_assim[k] != 0;
+    coef[(size_t)k * efa::kCoefStride + 3] = on ? 1.0 : 0.0;
+    if (on) {
+      if (!(ob_halfwidth_km[k] == ob_halfwidth_km[k]) || ob_halfwidth_km[k] == 0.0)
+        return fail(EFA_ERR_INVALID, "observation %ld: localize_radius must be a non-zero number", k);
+      hw[k] = ob_halfwidth_km[k];
+    }
+  }
+  EFA_TRY(h2d(c, c->gcc_lat, grid_lat, (size_t)ncol * sizeof(double)));
+  EFA_TRY(h2d(c, c->gcc_lon, grid_lon, (size_t)ncol * sizeof(double)));
+  EFA_TRY(h2d(c, c->gcc_oblat, ob_lat, (size_t)P * sizeof(double)));
+  EFA_TRY(h2d(c, c->gcc_oblon, ob_lon, (size_t)P * sizeof(double)));
+  EFA_TRY(h2d(c, c->gcc_obhw, hw.data(), (size_t)P * sizeof(double)));
+  EFA_TRY(h2d(c, c->gcc_coef, coef.data(), (size_t)P * efa::kCoefStride * sizeof(double)));
+  EFA_TRY(c->gcc_trig.reserve((size_t)(P ? P : 1) * 6 * sizeof(double)));
+  EFA_TRY(c->gcc_cnt.reserve((size_t)2 * nblk * sizeof(int)));  // [counts | pairs]
+  EFA_TRY(c->gcc_pairs.reserve(sizeof(unsigned long long)));
+  EFA_HIP(hipMemsetAsync(c->gcc_pairs.p, 0, sizeof(unsigned long long), s));
+  EFA_HIP(hipMemsetAsync(c->gcc_cnt.p, 0, (size_t)2 * nblk * sizeof(int), s));
+  if (P > 0)
+    EFA_HIP(efa::launch_gc_count(ncol, P, c->gcc_lat.as<double>(), c->gcc_lon.as<double>(), c->gcc_oblat.as<double>(),
+                                 c->gcc_oblon.as<double>(), c->gcc_obhw.as<double>(), c->gcc_coef.as<double>(),
+                                 c->gcc_trig.as<double>(), c->gcc_cnt.as<int>(), c->gcc_cnt.as<int>() + nblk,
+                                 c->gcc_pairs.as<unsigned long long>(), s));
+  unsigned long long pairs = 0;
+  EFA_HIP(hipMemcpyAsync(block_count, c->gcc_cnt.p, (size_t)nblk * sizeof(int), hipMemcpyDeviceToHost, s));
+  if (block_pairs)
+    EFA_HIP(hipMemcpyAsync(block_pairs, c->gcc_cnt.as<int>() + nblk, (size_t)nblk * sizeof(int), hipMemcpyDeviceToHost, s));
+  EFA_HIP(hipMemcpyAsync(&pairs, c->gcc_pairs.p, sizeof(pairs), hipMemcpyDeviceToHost, s));
+  EFA_HIP(hipStreamSynchronize(s));
+  if (active_pairs) *active_pairs = pairs;
   return EFA_OK;
 }
 

@@ -159,6 +159,9 @@ __global__ __launch_bounds__(kScanThreads) void k_gc_order(long nblk, const int*
   }
 }
 
+// COUNT_ONLY: the same pass without the lists -- cnt[b] and the pair total only (efa_gc_block_counts: the cost of a
+// column block for the cost-balanced column split of distributed.py)
+template <bool COUNT_ONLY>
 __global__ __launch_bounds__(64 * kBuildWaves) void k_gc_build(long ncol, long nblk, long P,
                                                                const double* __restrict__ glat,
                                                                const double* __restrict__ glon,
@@ -180,7 +183,7 @@ __global__ __launch_bounds__(64 * kBuildWaves) void k_gc_build(long ncol, long n
   const double cg = cos(radians(la)), sg = sin(radians(la)), cl = cos(radians(lo)), sl = sin(radians(lo));
   double la_lo, la_hi;
   block_lat_range(col_ok, la, la_lo, la_hi);
-  const long first = off[b];
+  const long first = COUNT_ONLY ? 0 : off[b];
   long running = first;
   long pairs = 0;  // (column, observation) pairs with a non-zero taper: SURVEY.md 8d's bytes_touched
   for (long k0 = 0; k0 < P; k0 += 64) {
@@ -215,7 +218,7 @@ __global__ __launch_bounds__(64 * kBuildWaves) void k_gc_build(long ncol, long n
         before += (i < o) ? f : 0;
         total += f;
       }
-      if (((bal >> (16 * o)) & 0xFFFFull) != 0ull) {
+      if (!COUNT_ONLY && ((bal >> (16 * o)) & 0xFFFFull) != 0ull) {
         const long e = running + before;
         if (c == 0) idx[e] = (int)k;
         wts[e * kBlkCols + c] = w;
@@ -225,6 +228,7 @@ __global__ __launch_bounds__(64 * kBuildWaves) void k_gc_build(long ncol, long n
   }
   if (lane == 0) {
     cnt[b] = (int)(running - first);
+    if (COUNT_ONLY && idx) idx[b] = (int)pairs;  // counting pass: the block's (column, observation) pairs
     if (npairs) atomicAdd(npairs, (unsigned long long)pairs);
   }
 }
@@ -273,7 +277,11 @@ __global__ __launch_bounds__(256, (NC * (RPL + 1) <= 30) ? EFA_GC_MINWAVES : (NC
   const int tid = threadIdx.x;
   const int wave = tid >> 6, lane = tid & 63;
   const int j = lane & 3, r = lane >> 2;
-  const long b = a.order[blockIdx.x];
+  // blockIdx.x = (position in the longest-first order) * lead_split + (group of slabs): a shard with few, long
+  // column blocks (the polar ranks of a cost-balanced split) still fills the device and has no tail of whole blocks
+  const long b = a.order[blockIdx.x / a.lead_split];
+  const long lead_lo = (long)(blockIdx.x % a.lead_split) * a.lead_chunk;
+  const long lead_hi = (lead_lo + a.lead_chunk < a.n_lead) ? lead_lo + a.lead_chunk : a.n_lead;
   // quad r of wave w: column cq of the block, slab slot sq of the group of slabs
   const int cq = EFA_GC_COLSPLIT ? 4 * wave + (r & 3) : r;
   const int sq = EFA_GC_COLSPLIT ? (r >> 2) : wave;
@@ -286,7 +294,7 @@ __global__ __launch_bounds__(256, (NC * (RPL + 1) <= 30) ? EFA_GC_MINWAVES : (NC
   // A quad holds RPL rows of the SAME column (slabs lead, lead + 4, ...): they share the taper and
   // every ye row read from LDS (the quad layout delivers each ye row once per quad), and a staged
   // chunk serves 4 RPL slabs instead of 4.
-  for (long lead0 = 0; lead0 < a.n_lead; lead0 += 4 * RPL) {
+  for (long lead0 = lead_lo; lead0 < lead_hi; lead0 += 4 * RPL) {
     double x[RPL][2 * NC];
     double xm[RPL];
     bool live[RPL];
@@ -295,7 +303,7 @@ __global__ __launch_bounds__(256, (NC * (RPL + 1) <= 30) ? EFA_GC_MINWAVES : (NC
 #pragma unroll
     for (int q = 0; q < RPL; ++q) {
       const long lead = lead0 + sq + 4 * q;
-      live[q] = col_ok && lead < a.n_lead;
+      live[q] = col_ok && lead < lead_hi;
       any_live = any_live || live[q];
       row[q] = lead * a.ncol + col;
       xm[q] = 0.0;
@@ -376,10 +384,25 @@ __global__ __launch_bounds__(256, (NC * (RPL + 1) <= 30) ? EFA_GC_MINWAVES : (NC
 inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
 
 template <int NC>
-hipError_t gc_launch(const GcSweepArgs& a, hipStream_t s) {
+hipError_t gc_launch(const GcSweepArgs& a0, hipStream_t s) {
+  GcSweepArgs a = a0;
   const bool vec = (a.M % 2 == 0) && (a.ye_stride % 2 == 0) && aligned16(a.Xin) && aligned16(a.Xout) && aligned16(a.Ye);
-  const dim3 grid((unsigned)a.nblk), block(256);
   constexpr int RPL = (NC <= 13) ? EFA_GC_RPL : 1;  // two rows per quad while they fit the register file
+  // groups of slabs per column block: whole iterations of the slab loop (4 RPL slabs), as many as it takes to give
+  // every CU a dozen workgroups, at most one group per iteration
+  static int cus = 0;
+  if (cus == 0) {
+    int dev = 0, n = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
+    cus = n;
+  }
+  const long iters = (a.n_lead + 4 * RPL - 1) / (4 * RPL);
+  long split = (12L * cus + a.nblk - 1) / a.nblk;
+  if (split > iters) split = iters;
+  if (split < 1) split = 1;
+  a.lead_chunk = ((iters + split - 1) / split) * (4 * RPL);
+  a.lead_split = (int)((a.n_lead + a.lead_chunk - 1) / a.lead_chunk);
+  const dim3 grid((unsigned)(a.nblk * a.lead_split)), block(256);
   if (a.fused_members) {
     if (vec) hipLaunchKernelGGL((k_sweep_gc<NC, true, true, RPL>), grid, block, 0, s, a);
     else hipLaunchKernelGGL((k_sweep_gc<NC, false, true, RPL>), grid, block, 0, s, a);
@@ -410,11 +433,22 @@ hipError_t launch_gc_fill(long ncol, long P, const double* glat, const double* g
   const long nblk = gc_num_blocks(ncol);
   if (nblk <= 0) return hipSuccess;
   hipLaunchKernelGGL(k_gc_obtrig, dim3((unsigned)((P + 255) / 256)), dim3(256), 0, s, P, ob_lat, ob_lon, ob_hw, obtrig);
-  hipLaunchKernelGGL(k_gc_build, dim3((unsigned)((nblk + kBuildWaves - 1) / kBuildWaves)), dim3(64 * kBuildWaves), 0, s,
+  hipLaunchKernelGGL(k_gc_build<false>, dim3((unsigned)((nblk + kBuildWaves - 1) / kBuildWaves)), dim3(64 * kBuildWaves), 0, s,
                      ncol, nblk, P, glat, glon, ob_lat, ob_lon, ob_hw, coef, obtrig, cnt, off, idx, wts, npairs);
   int shift = 0;
   while ((P >> shift) >= kScanThreads) ++shift;
   hipLaunchKernelGGL(k_gc_order, dim3(1), dim3(kScanThreads), 0, s, nblk, cnt, shift, order);
+  return hipGetLastError();
+}
+
+hipError_t launch_gc_count(long ncol, long P, const double* glat, const double* glon, const double* ob_lat,
+                           const double* ob_lon, const double* ob_hw, const double* coef, double* obtrig, int* cnt,
+                           int* blk_pairs, unsigned long long* npairs, hipStream_t s) {
+  const long nblk = gc_num_blocks(ncol);
+  if (nblk <= 0) return hipSuccess;
+  hipLaunchKernelGGL(k_gc_obtrig, dim3((unsigned)((P + 255) / 256)), dim3(256), 0, s, P, ob_lat, ob_lon, ob_hw, obtrig);
+  hipLaunchKernelGGL(k_gc_build<true>, dim3((unsigned)((nblk + kBuildWaves - 1) / kBuildWaves)), dim3(64 * kBuildWaves), 0, s,
+                     ncol, nblk, P, glat, glon, ob_lat, ob_lon, ob_hw, coef, obtrig, cnt, nullptr, blk_pairs, nullptr, npairs);
   return hipGetLastError();
 }
 

@@ -137,6 +137,8 @@ struct GcSweepArgs {
   double* Xout;
   double* xout;
   int fused_members;
+  int lead_split;       // set by the launcher: groups of slabs a column block is cut into (one workgroup each)
+  long lead_chunk;      // slabs per group
 };
 long gc_num_blocks(long ncol);
 // list build in one pass: upper bounds + device prefix sum (off[nblk] = capacity needed), then the entries
@@ -146,6 +148,11 @@ hipError_t launch_gc_fill(long ncol, long P, const double* glat, const double* g
                           const double* ob_lon, const double* ob_hw, const double* coef, double* obtrig /* [P][6] scratch */,
                           const long* off, int* cnt, int* idx, double* wts, int* order, unsigned long long* npairs,
                           hipStream_t s);
+// the counting half of the list build alone: cnt[b] = observations with a non-zero taper on any of block b's 16 columns
+hipError_t launch_gc_count(long ncol, long P, const double* glat, const double* glon, const double* ob_lat,
+                           const double* ob_lon, const double* ob_hw, const double* coef, double* obtrig /* [P][6] scratch */,
+                           int* cnt, int* blk_pairs /* [nblk] (column, ob) pairs of each block, or null */,
+                           unsigned long long* npairs, hipStream_t s);
 hipError_t launch_sweep_gc(const GcSweepArgs& a, hipStream_t s);
 
 struct TransformArgs {

@@ -11,8 +11,18 @@ Rows of the state are independent given the obs-space trajectory (DESIGN.md,
 "F1"), so after ONE sum all-reduce of the forward-operator output HX (P x M
 doubles; each rank contributes the stencil points it owns) every rank holds the
 identical obs block, runs Phase A redundantly and sweeps only its own rows.
-There is no per-observation communication.  With `torch.distributed` backend
-"nccl" the all-reduce is RCCL over xGMI.
+There is no per-observation communication.  The all-reduce is RCCL over xGMI,
+issued by the library itself on the context's stream (`efa_comm_init` /
+`efa_allreduce_sum_dev`, include/efa_hip.h); `torch.distributed` is only the
+rendezvous that carries the 128-byte communicator id to the other ranks (and the
+barrier of the bench).
+
+Partition.  Without localisation every column costs the same and the split is the
+reference sketch's: contiguous equal chunks.  With Gaspari-Cohn localisation the
+work of a column is the number of observations whose taper reaches it, which on a
+lat/lon grid grows several-fold towards the poles; `balanced_column_bounds` cuts
+the same contiguous order at equal cumulative cost instead
+(`efa_gc_block_counts` counts the active list of every 16-column block on the device).
 
 The arithmetic is delegated to an *engine* with the methods of
 `HipEngine`; the product engine is the HIP library.  (Tests drive the same host
@@ -30,6 +40,35 @@ def column_bounds(ncol, world_size):
     if chunk == 0:
         raise ValueError("more ranks (%d) than columns (%d)" % (world_size, ncol))
     return [(r * chunk, (r + 1) * chunk if r != world_size - 1 else ncol) for r in range(world_size)]
+
+
+GC_BLOCK = 16          # columns per block of the one-pass localised sweep (efa_gcsweep.hip)
+# A block's read + write of its rows, in (column, ob) pairs.  Calibrated on configs[3] on one MI355X: the sweep spends
+# 0.41 us of one CU per pair (148 slabs x 100 members) and a block's 3.8 MB take 0.22 ms of one CU's share of HBM.
+GC_FIXED_COST = 512.0
+
+
+def balanced_column_bounds(block_pairs, ncol, world_size, block=GC_BLOCK, fixed=GC_FIXED_COST):
+    """[(lo, hi)] per rank: contiguous column ranges, cut on block boundaries so that every rank gets the same
+    share of sum(block_pairs + fixed).  `block_pairs[b]` = (column, observation) pairs with a non-zero taper in
+    block b: the sweep's waves skip an ob that is zero on their columns, so its work follows the pairs.  Falls back
+    to equal chunks when there are fewer blocks than ranks."""
+    cost = np.asarray(block_pairs, dtype=np.float64) + float(fixed)
+    nblk = cost.shape[0]
+    assert nblk == (ncol + block - 1) // block
+    if nblk < world_size:
+        return column_bounds(ncol, world_size)
+    cum = np.concatenate(([0.0], np.cumsum(cost)))
+    cuts = [0]
+    for r in range(1, world_size):
+        target = cum[-1] * r / world_size
+        b = int(np.searchsorted(cum, target))            # first block boundary at or beyond the target
+        if b > 0 and target - cum[b - 1] < cum[b] - target:
+            b -= 1                                        # the nearer of the two boundaries
+        b = min(max(b, cuts[-1] + 1), nblk - (world_size - r))   # every rank keeps at least one block
+        cuts.append(b)
+    cuts.append(nblk)
+    return [(cuts[r] * block, min(cuts[r + 1] * block, ncol)) for r in range(world_size)]
 
 
 def shard_rows(n_lead, ncol, lo, hi):
@@ -61,6 +100,26 @@ class HipEngine(object):
         torch.cuda.set_device(device)
         self.ctx = _lib.Context(device)
         self.ctx.set_stream(torch.cuda.current_stream().cuda_stream)
+        self.has_comm = False
+
+    def init_comm(self, rank, world_size, group=None):
+        """Create the library-owned RCCL communicator.  Collective over `group` (torch.distributed, any
+        backend): rank 0's id travels as a broadcast object; at world size 1 nothing else is needed."""
+        cid = [self.ctx.comm_unique_id() if rank == 0 else None]
+        if world_size > 1:
+            import torch.distributed as dist
+            dist.broadcast_object_list(cid, src=0, group=group)
+        self.ctx.comm_init(cid[0], rank, world_size)
+        self.has_comm = True
+
+    def all_reduce_sum(self, t):
+        """Sum over the ranks through the context's own communicator, on the context's stream."""
+        assert self.has_comm and t.is_contiguous()
+        self.ctx.allreduce_sum(t.data_ptr(), t.numel())
+        return t
+
+    def gc_block_counts(self, grid_lat, grid_lon, ob):
+        return self.ctx.gc_block_counts(grid_lat, grid_lon, ob["lat"], ob["lon"], ob["halfwidth"], ob["assim"])
 
     def empty(self, shape):
         return self.torch.empty(shape, dtype=self.torch.float64, device=self.device)
@@ -96,20 +155,39 @@ class ShardedEnSRF(object):
     grid_lat/grid_lon : (ncol,) per-column lat/lon of the GLOBAL grid (GC only).
     """
 
-    def __init__(self, engine, n_lead, ncol, M, rank=0, world_size=1, group=None):
+    def __init__(self, engine, n_lead, ncol, M, rank=0, world_size=1, group=None, bounds=None):
         self.engine = engine
         self.n_lead, self.ncol, self.M = int(n_lead), int(ncol), int(M)
         self.rank, self.world_size, self.group = rank, world_size, group
-        self.lo, self.hi = column_bounds(self.ncol, world_size)[rank]
+        self.bounds = list(bounds) if bounds is not None else column_bounds(self.ncol, world_size)
+        assert len(self.bounds) == world_size and self.bounds[0][0] == 0 and self.bounds[-1][1] == self.ncol
+        assert all(a[1] == b[0] for a, b in zip(self.bounds[:-1], self.bounds[1:]))
+        self.lo, self.hi = self.bounds[rank]
         self.rows_local = self.n_lead * (self.hi - self.lo)
+
+    @classmethod
+    def balanced(cls, engine, n_lead, ncol, M, ob, grid_lat, grid_lon, rank=0, world_size=1, group=None):
+        """Shards of equal COST for a localised cycle: every rank counts the active lists of the global grid's
+        column blocks (the same deterministic count everywhere, a few ms on the device) and cuts the contiguous
+        column order at equal cumulative cost.  Without localisation: the equal split."""
+        if ob.get("loc") != "GC" or world_size == 1:
+            return cls(engine, n_lead, ncol, M, rank, world_size, group)
+        _, blk_pairs, _ = engine.gc_block_counts(grid_lat, grid_lon, ob)
+        return cls(engine, n_lead, ncol, M, rank, world_size, group,
+                   bounds=balanced_column_bounds(blk_pairs, int(ncol), world_size))
 
     def local_rows(self):
         return shard_rows(self.n_lead, self.ncol, self.lo, self.hi)
 
     def all_reduce_sum(self, t):
+        """The one exchange step.  An engine that owns a communicator (HipEngine after `init_comm`: RCCL inside
+        libefa_hip) performs it; otherwise `torch.distributed` does (CPU ranks under gloo in the tests)."""
         if self.world_size > 1:
-            import torch.distributed as dist
-            dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group)
+            if getattr(self.engine, "has_comm", False):
+                self.engine.all_reduce_sum(t)
+            else:
+                import torch.distributed as dist
+                dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group)
         return t
 
     def partial_estimates(self, X_local, sten_idx, sten_wts, inflation=None):

@@ -276,6 +276,46 @@ int efa_last_timing(efa_ctx *ctx, double *state_ms, double *obs_ms,
 int efa_fill_synthetic_dev(efa_ctx *ctx, long rows, long row_offset, int M,
                            uint64_t seed, double sigma, double *X_dev);
 
+/* ---- multi-GPU, one process per GPU ----------------------------
+ * The reference has no working multi-process path; its sketch (assimilation.py:186-193,
+ * ensemble.py:98-106) computes the obs priors once and hands them to every
+ * worker.  Here the state is sharded by (y,x) column; each rank calls
+ * efa_forward_interp_dev / efa_forward_stencil_dev on its own columns and the
+ * P x M partial sums are added over the ranks by ONE all-reduce
+ * (ncclAllReduce, sum, float64, over xGMI) issued on the context's stream.
+ * Afterwards every rank runs efa_obs_phase_dev on the identical obs block and
+ * efa_state_cycle_dev on its own rows: no per-observation communication.
+ *
+ * The communicator lives inside the context.  librccl is opened with dlopen by
+ * efa_comm_unique_id / efa_comm_init, so single-GPU callers never load it.
+ * Rank 0 obtains an id and hands the EFA_COMM_ID_BYTES bytes to the other
+ * ranks by any means (MPI, a file, torch.distributed); then every rank calls
+ * efa_comm_init collectively. */
+#define EFA_COMM_ID_BYTES 128
+int efa_comm_unique_id(uint8_t *id_out /* [EFA_COMM_ID_BYTES] */);
+int efa_comm_init(efa_ctx *ctx, const uint8_t *id, int rank, int world);
+int efa_comm_destroy(efa_ctx *ctx);
+/* buf_dev[count] <- sum over ranks, in place, on the context's stream (asynchronous:
+ * ordered before whatever is issued on the context afterwards) */
+int efa_allreduce_sum_dev(efa_ctx *ctx, double *buf_dev, long count);
+
+/* Cost of the localised state sweep per block of 16 consecutive (y,x) columns
+ * of a grid: block_count[b] = number of assimilated observations whose
+ * Gaspari-Cohn weight (observation.py:117-130 on ensemble.py:254-267 distances) is
+ * non-zero on at least one of columns 16b..16b+15 -- the length of the block's
+ * active list in the one-pass sweep; block_pairs[b] (optional) = (column,
+ * observation) pairs with a non-zero weight inside the block (the sweep's waves
+ * skip an observation that is zero on their four columns, so its work follows the
+ * pairs); *active_pairs = their total.  Host arrays of (ncol+15)/16 entries.
+ * Used to cut the columns into contiguous shards of equal cost
+ * (the reference's sketch cuts equal chunks, ensemble.py:98-106, which leaves
+ * polar shards of a lat/lon grid with several times the work). */
+int efa_gc_block_counts(efa_ctx *ctx, long ncol, const double *grid_lat,
+                        const double *grid_lon, long P, const double *ob_lat,
+                        const double *ob_lon, const double *ob_halfwidth_km,
+                        const uint8_t *ob_assim, int32_t *block_count,
+                        int32_t *block_pairs, uint64_t *active_pairs);
+
 #ifdef __cplusplus
 }
 #endif

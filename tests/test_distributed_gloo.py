@@ -55,6 +55,9 @@ class OracleEngine(object):
                                            ob["assim"], **kw)
         return diag
 
+    def gc_block_counts(self, grid_lat, grid_lon, ob):
+        return numpy_block_counts(self.orc, grid_lat, grid_lon, ob)
+
     def state_cycle(self, rows, M, X, post, grid_lat, grid_lon, n_lead):
         x = X.numpy()
         xm = x.mean(axis=1)
@@ -67,6 +70,24 @@ class OracleEngine(object):
                       grid_lat=grid_lat, grid_lon=grid_lon, state_shape=(n_lead, 1, 1, rows // n_lead))
         xam, Xap, _ = self.orc.ensrf_update(xbm, Xbp, rows, ob["value"], ob["error"], ob["assim"], **kw)
         post.copy_(torch.from_numpy(self.orc.format_posterior_state(xam, Xap, rows)))
+
+
+def numpy_block_counts(orc, grid_lat, grid_lon, ob, block=16):
+    """What efa_gc_block_counts computes, with the oracle's distance and taper (ensemble.py:254-267,
+    observation.py:117-130): per block of 16 columns the assimilated obs with a non-zero weight on any of them."""
+    glat = np.asarray(grid_lat, dtype=np.float64).reshape(-1)
+    glon = np.asarray(grid_lon, dtype=np.float64).reshape(-1)
+    ncol = glat.shape[0]
+    nblk = (ncol + block - 1) // block
+    cnt = np.zeros(nblk, dtype=np.int64)
+    blk_pairs = np.zeros(nblk, dtype=np.int64)
+    for k in np.nonzero(np.asarray(ob["assim"]))[0]:
+        w = orc.gaspari_cohn(orc.distance_to_point(glat, glon, ob["lat"][k], ob["lon"][k]), ob["halfwidth"][k]) != 0.0
+        pad = np.zeros(nblk * block, dtype=bool)
+        pad[:ncol] = w
+        cnt += pad.reshape(nblk, block).any(axis=1)
+        blk_pairs += pad.reshape(nblk, block).sum(axis=1)
+    return cnt, blk_pairs, int(blk_pairs.sum())
 
 
 def _problem(loc):
@@ -95,7 +116,12 @@ def _worker(rank, world, port, loc, q):
     try:
         from efa_xray_amd.distributed import ShardedEnSRF
         pr = _problem(loc)
-        sh = ShardedEnSRF(OracleEngine(), pr["n_lead"], pr["ncol"], pr["M"], rank=rank, world_size=world)
+        if loc == "balanced":   # cost-balanced contiguous shards (Gaspari-Cohn): cut at 16-column block boundaries
+            sh = ShardedEnSRF.balanced(OracleEngine(), pr["n_lead"], pr["ncol"], pr["M"], pr["ob"], pr["lat"].reshape(-1),
+                                       pr["lon"].reshape(-1), rank=rank, world_size=world)
+            assert sh.bounds != ShardedEnSRF(OracleEngine(), pr["n_lead"], pr["ncol"], pr["M"], rank, world).bounds
+        else:
+            sh = ShardedEnSRF(OracleEngine(), pr["n_lead"], pr["ncol"], pr["M"], rank=rank, world_size=world)
         rows = sh.local_rows()
         Xl = torch.from_numpy(np.ascontiguousarray(pr["X"][rows]))
         post = torch.zeros_like(Xl)
@@ -120,7 +146,7 @@ def _free_port():
     return p
 
 
-@pytest.mark.parametrize("world,loc", [(2, False), (2, True), (3, True)])
+@pytest.mark.parametrize("world,loc", [(2, False), (2, True), (3, True), (3, "balanced")])
 def test_sharded_cycle_equals_unsharded_oracle(world, loc):
     from oracle import ensrf_oracle as orc
     ctx = mp.get_context("spawn")
@@ -166,3 +192,39 @@ def test_column_bounds_and_stencil_localisation():
                 assert rows[li[0, j]] == idx[0, j]
         tot += lw.sum()
     assert abs(tot - 1.0) < 1e-15          # every stencil point owned exactly once
+
+
+def test_cost_balanced_column_bounds_on_a_global_grid():
+    """Gaspari-Cohn work per column grows towards the poles of a lat/lon grid (obs drawn uniformly over grid points
+    are dense per km^2 there and every footprint spans many longitudes): the equal split of ensemble.py:98-106 leaves
+    the polar ranks with a multiple of the mean work, the cost-balanced contiguous split stays within 5 %."""
+    from oracle import ensrf_oracle as orc
+    from efa_xray_amd.distributed import balanced_column_bounds, column_bounds, GC_FIXED_COST
+    ny, nx, P = 61, 120, 1500
+    lat, lon = np.meshgrid(np.linspace(-90, 90, ny), np.linspace(0, 357, nx), indexing="ij")
+    glat, glon = lat.reshape(-1), lon.reshape(-1)
+    ncol = ny * nx
+    rng = np.random.default_rng(9)
+    col = rng.choice(ncol, P, replace=False)
+    ob = dict(lat=glat[col], lon=glon[col], halfwidth=np.full(P, 1000.0), assim=rng.random(P) > 0.1)
+    cnt, bp, pairs = numpy_block_counts(orc, glat, glon, ob)
+    assert pairs > 0 and bp.max() > 2 * np.median(bp)
+    cost = bp + GC_FIXED_COST
+
+    def shares(bounds):
+        return np.array([cost[lo // 16:(hi + 15) // 16].sum() for lo, hi in bounds])
+
+    for world in (2, 3, 4, 8):
+        b = balanced_column_bounds(bp, ncol, world)
+        assert b[0][0] == 0 and b[-1][1] == ncol and all(x[1] == y[0] for x, y in zip(b[:-1], b[1:]))
+        assert all(lo % 16 == 0 for lo, _ in b) and all(hi > lo for lo, hi in b)
+        s = shares(b)
+        assert s.max() / s.mean() <= 1.05, (world, s)
+    eq = column_bounds(ncol, 8)
+    eq = [(lo - lo % 16, hi - hi % 16 if hi != ncol else hi) for lo, hi in eq]
+    s_eq = shares(eq)
+    assert s_eq.max() / s_eq.mean() > 1.3       # what the equal split costs
+    # degenerate inputs: fewer blocks than ranks -> the equal split; no obs -> equal blocks
+    assert balanced_column_bounds(np.zeros(1), 10, 3) == column_bounds(10, 3)
+    b0 = balanced_column_bounds(np.zeros(8), 128, 4)
+    assert b0 == [(0, 32), (32, 64), (64, 96), (96, 128)]
