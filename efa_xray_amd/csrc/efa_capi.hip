@@ -7,6 +7,7 @@
 
 #include <dlfcn.h>
 
+#include <cmath>
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
@@ -145,7 +146,7 @@ struct efa_ctx {
   PinBuf pin_in, pin_out;    // their pinned host images: one H2D and one D2H per call
   PinBuf pin_fs;             // pinned image of the forward-operator stencil
   hipEvent_t ev_fs = nullptr;  // its last host-to-device copy
-  DevBuf ob_val, ob_err, ob_asm, ob_lat, ob_lon, ob_hw;  // device copies [P]
+  DevBuf ob_val, ob_err, ob_asm, ob_lat, ob_lon, ob_hw, ob_errsq;  // device copies [P] ([P][2] the last)
   DevBuf d_prior_mean, d_prior_var, d_post_mean, d_post_var, d_assimilated;
   DevBuf Yw, ymw;  // obs block workspace [(P+M)][M], [(P+M)]
   // --- state phase workspaces ---------------------------------------------
@@ -255,7 +256,7 @@ int obs_phase(efa_ctx* c, int M, long P, double* ym_dev, double* Yp_dev, const d
   {
     const bool gc = loc_mode == EFA_LOC_GC;
     const size_t slot = ((size_t)P * sizeof(double) + 255) & ~(size_t)255;
-    const size_t total = 6 * slot;
+    const size_t total = 8 * slot;  // ... | {error, sqrt(error)} pairs: the band leader's per-ob constants, fetched by scalar loads
     EFA_TRY(c->ob_pack.reserve(total));
     EFA_TRY(c->pin_in.reserve(total));
     char* hb = static_cast<char*>(c->pin_in.p);
@@ -268,6 +269,14 @@ int obs_phase(efa_ctx* c, int M, long P, double* ym_dev, double* Yp_dev, const d
       std::memcpy(hb + 4 * slot, ob_hw, dP);
     }
     std::memcpy(hb + 5 * slot, ob_assim, (size_t)P);
+    {
+      double* ec = reinterpret_cast<double*>(hb + 6 * slot);
+      for (long k = 0; k < P; ++k) {
+        ec[2 * k] = ob_error[k];
+        ec[2 * k + 1] = std::sqrt(ob_error[k]);
+      }
+    }
+    c->ob_errsq.carve(db + 6 * slot, 2 * slot);
     c->ob_val.carve(db, slot);
     c->ob_err.carve(db + slot, slot);
     c->ob_lat.carve(db + 2 * slot, slot);
@@ -278,7 +287,7 @@ int obs_phase(efa_ctx* c, int M, long P, double* ym_dev, double* Yp_dev, const d
       EFA_HIP(hipMemcpyAsync(db, hb, total, hipMemcpyHostToDevice, c->stream));
     } else {
       EFA_HIP(hipMemcpyAsync(db, hb, 2 * slot, hipMemcpyHostToDevice, c->stream));
-      EFA_HIP(hipMemcpyAsync(db + 5 * slot, hb + 5 * slot, (size_t)P, hipMemcpyHostToDevice, c->stream));
+      EFA_HIP(hipMemcpyAsync(db + 5 * slot, hb + 5 * slot, 3 * slot, hipMemcpyHostToDevice, c->stream));
     }
   }
   EFA_TRY(c->Ye_rec.reserve((size_t)P * M * sizeof(double)));
@@ -326,6 +335,7 @@ int obs_phase(efa_ctx* c, int M, long P, double* ym_dev, double* Yp_dev, const d
     pa.ob_value = c->ob_val.as<double>();
     pa.ob_error = c->ob_err.as<double>();
     pa.ob_assim = c->ob_asm.as<uint8_t>();
+    pa.ob_errsq = c->ob_errsq.as<double>();
     pa.loc_mode = loc_mode;
     pa.tw = nullptr;
     if (loc_mode == EFA_LOC_GC) {
@@ -748,7 +758,7 @@ int efa_ctx_destroy(efa_ctx* c) {
   c->pin_out.release();
   c->pin_fs.release();
   if (c->ev_fs) (void)hipEventDestroy(c->ev_fs);
-  DevBuf* bufs[] = {&c->ob_pack, &c->out_pack, &c->Ye_rec, &c->coef, &c->ob_val, &c->ob_err, &c->ob_asm, &c->ob_lat, &c->ob_lon, &c->ob_hw,
+  DevBuf* bufs[] = {&c->ob_pack, &c->out_pack, &c->Ye_rec, &c->coef, &c->ob_val, &c->ob_err, &c->ob_asm, &c->ob_lat, &c->ob_lon, &c->ob_hw, &c->ob_errsq,
                     &c->d_prior_mean, &c->d_prior_var, &c->d_post_mean, &c->d_post_var, &c->d_assimilated,
                     &c->Yw, &c->ymw, &c->traj, &c->tw_mat, &c->status, &c->dbg, &c->W, &c->gc_cnt, &c->gc_ub, &c->gc_order, &c->gc_obtrig, &c->gc_off, &c->gc_idx, &c->gc_wts, &c->gc_pairs, &c->glat, &c->glon, &c->xm_ws, &c->fs_idx, &c->fs_wts, &c->f_glat, &c->f_glon, &c->f_sl, &c->f_cl, &c->f_valids, &c->f_var, &c->f_time, &c->f_lat, &c->f_lon, &c->f_near, &c->f_idx, &c->f_wts, &c->f_status, &c->h_xm, &c->h_Xp, &c->h_ym, &c->h_Yp,
                     &c->gcc_lat, &c->gcc_lon, &c->gcc_oblat, &c->gcc_oblon, &c->gcc_obhw, &c->gcc_coef, &c->gcc_trig, &c->gcc_cnt, &c->gcc_pairs};

@@ -59,8 +59,16 @@ constexpr int kNBands = kRowsWG / kBand;
 static_assert(PLg == 4 && kRowsWG == 64, "layout assumptions of the band kernel");
 
 // control words (ints in LDS)
+static_assert(true, "");
 enum { cReady = 0, cBail = 1, cSReady = 2, cFwd = 3, cProg = 4 /* ..7 */, cBandH = 8 /* ..9 */, cLinv = 10, cPark = 11, cYe = 12, cHalf = 13 };
-constexpr int kEarly = kBand / 2;  // steps of a band the G waves have applied to the next band's rows when they hand them over
+#ifndef EFA_EARLY
+#define EFA_EARLY 1
+#endif
+#ifndef EFA_G_DEFER
+#define EFA_G_DEFER 0  // 1: the G waves owe a band's trailing update until after the next band's early rows (measured: slower)
+#endif
+constexpr int kEarly = EFA_EARLY;  // steps of a band the G waves have applied to the next band's rows when they hand them over
+static_assert(kEarly >= 1 && kEarly < kBand, "early hand-over");
 constexpr int kScStride = 4;  // doubles per ob: rden, beta (latched by the pivot wave), innov, active (added by the forwarder): the record's scalars
 
 __device__ __forceinline__ u64 g_traj_load(const u64* p) {
@@ -89,6 +97,24 @@ __device__ __forceinline__ double g_rcp(double b) {
   const double r = __builtin_amdgcn_rcp(b);
   const double e = __builtin_fma(-b, r, 1.0);
   return __builtin_fma(r, __builtin_fma(e, e, e), r);
+}
+// The gain chain of one observation from its obs-space variance G_kk / M and error variance (ensrf.py:91, :119, :135):
+//   kdenom -> q0 = rsq(kdenom) -> { Newton step of q  ||  beta0 = 1/(1 + sqrt(err) q0) } -> rden = 1/kdenom, beta.
+// The pivot wave (on the serial chain) and the forwarder wave (for the records and diagnostics) both call it on the same
+// inputs, so they hold the same bits without handing them to each other.
+__device__ __forceinline__ void gain_scalars(double Gkk, double invM, double errk, double sqk, double& rden, double& beta) {
+  const double kdenom = __builtin_fma(Gkk, invM, errk);         // var + err  (:69, :91)
+  const double q0 = __builtin_amdgcn_rsq(kdenom);
+  const double e = __builtin_fma(-kdenom * q0, q0, 1.0);
+  const double d = e * __builtin_fma(0.375, e, 0.5);            // q = q0 (1 + d)
+  const double q = __builtin_fma(q0, d, q0);
+  rden = q * q;                                                 // 1 / kdenom
+  const double sq0 = sqk * q0;
+  const double b0 = 1.0 + sq0;
+  const double r0c = __builtin_amdgcn_rcp(b0);
+  const double eb = __builtin_fma(-b0, r0c, 1.0);
+  const double beta0 = __builtin_fma(r0c, __builtin_fma(eb, eb, eb), r0c);
+  beta = __builtin_fma(-((beta0 * beta0) * sq0), d, beta0);     // 1 / (1 + sqrt(err / kdenom))  (:135)
 }
 __device__ __forceinline__ double rl(double v, int lane) {  // value held by `lane` (wave-uniform index)
   const int lo = __builtin_amdgcn_readlane(__double2loint(v), lane);
@@ -126,8 +152,6 @@ __global__ __launch_bounds__(kGT) void k_pipe_band(const PipeArgs a) {
   int* ctl = reinterpret_cast<int*>(tw_s + Sh::kTw);  // [32]
   double* Yt = U;
   double2* s_gk = reinterpret_cast<double2*>(U);  // [step][row] = {G_kj, kb_j}
-  double* s_sc = U + 2 * kRowsWG * kRowsWG;       // [ob][4]  rden, beta | innov, active: the four scalars of the ob's record
-  double* s_var = s_sc + kRowsWG * kScStride;     // [ob]     prior variance (np.var, ddof 0) latched by the pivot wave
 
   const int tid = threadIdx.x;
   // wave roles: 0-3 vector, 4 pivot, 5-6 G waves, 7 loader
@@ -163,10 +187,17 @@ __global__ __launch_bounds__(kGT) void k_pipe_band(const PipeArgs a) {
 #else
 #define EFA_WAIT_OUT(cond, row, slot, v) do { } while (0)
 #endif
-#if defined(EFA_PIPE_STAMPS) || defined(EFA_PIPE_BLOCKTIME)
+#if defined(EFA_PIPE_STAMPS) || defined(EFA_PIPE_BLOCKTIME) || defined(EFA_PIPE_PIVSTAMP)
 #define EFA_EXP(bit) ((a.debug & (bit)) != 0)  /* timing experiments (diagnostic builds only): results are wrong */
 #else
 #define EFA_EXP(bit) false
+#endif
+#ifdef EFA_PIPE_PIVSTAMP  /* make pivstamp: wait / work accounting of the pivot and G waves only (they have registers to spare) */
+#define EFA_PS_NOW() __builtin_amdgcn_s_memtime()
+#define EFA_PS(stmt) stmt
+#else
+#define EFA_PS_NOW() 0ull
+#define EFA_PS(stmt)
 #endif
   long budget = a.spin_limit;
   // every spin is bounded twice: by a poll budget and by wall time (s_memrealtime, 100 MHz), looked at only on the
@@ -193,6 +224,24 @@ __global__ __launch_bounds__(kGT) void k_pipe_band(const PipeArgs a) {
       if (doze) __builtin_amdgcn_s_sleep(1);
     }
     return true;
+  };
+  // both G waves' hand-over words (adjacent ints, 8-byte aligned) in ONE LDS read per poll
+  auto wait_gt2 = [&](const int* word2, int thr) {
+    for (;;) {
+      const unsigned long long v = __hip_atomic_load(reinterpret_cast<const unsigned long long*>(word2), __ATOMIC_RELAXED,
+                                                     __HIP_MEMORY_SCOPE_WORKGROUP);
+      asm volatile("" ::: "memory");
+      const int lo = __builtin_amdgcn_readfirstlane((int)(v & 0xffffffffull)), hi = __builtin_amdgcn_readfirstlane((int)(v >> 32));
+      if (lo > thr && hi > thr) return true;
+      if ((++polls & 15) == 0) {
+        if (g_ctl(&ctl[cBail]) != 0) return false;
+        budget -= 16;
+        if (budget <= 0 || EFA_TIMED_OUT()) {
+          give_up();
+          return false;
+        }
+      }
+    }
   };
   // least-advanced consumer of the ye ring: the 4 vector waves and the forwarder
   auto min_prog = [&]() {
@@ -312,8 +361,10 @@ __global__ __launch_bounds__(kGT) void k_pipe_band(const PipeArgs a) {
       double xmv = pm[kRowsWG + lane];
       const bool f_ob = lane < nb;
       const double val_l = f_ob ? a.ob_value[own0 + lane] : 0.0;
+      const double2 ec_l = f_ob ? *reinterpret_cast<const double2*>(a.ob_errsq + 2 * (own0 + lane)) : make_double2(1.0, 1.0);
       const u64 asm_mask = __ballot(f_ob ? (a.ob_assim[own0 + lane] != 0) : false);
       double l_xm = 0.0;
+      double l_var = 0.0, l_rd = 0.0, l_be = 0.0;  // this lane's ob: prior variance, 1/kdenom, beta -- from G_kk at its step
       for (int b = 0; b < nbands && !failed; ++b) {
         // the band's ye rows are in the ring once every vector wave has added its tiles (4 per band)
         if (!wait_gt(&ctl[cYe], 4 * (b + 1) - 1, true)) {
@@ -321,12 +372,21 @@ __global__ __launch_bounds__(kGT) void k_pipe_band(const PipeArgs a) {
           break;
         }
         const int s1 = (nb - kBand * b < kBand) ? nb - kBand * b : kBand;
+        {  // the band's obs, one per lane: the scalars the pivot wave used at their steps, recomputed from the same G_kk
+          const double Gkk = s_gk[(lane & 63) * kRowsWG + lane].x;
+          double rd, be;
+          gain_scalars(Gkk, invM, ec_l.x, ec_l.y, rd, be);
+          const bool mine = (lane >> 2) == b;  // kBand == 4
+          l_rd = mine ? rd : l_rd;
+          l_be = mine ? be : l_be;
+          l_var = mine ? Gkk * invM : l_var;                                   // np.var, ddof = 0 (:69, :70): the rows are centred
+        }
         for (int s = 0; s < s1; ++s) {
           const int st = kBand * b + s;
           const long f = own0 + st;
           const double* slot = ring + (size_t)(f % kRingG) * TSR;
           const double2 gk = s_gk[st * kRowsWG + lane];                        // G_kj, kb_j of this lane's row
-          const double rden = s_sc[(size_t)st * kScStride];
+          const double rden = rl(l_rd, st), beta_k = rl(l_be, st);
           const bool act = ((asm_mask >> st) & 1) != 0;
           const double xmk = rl(xmv, st);
           const double innov = rl(val_l, st) - xmk;                            // :85
@@ -344,11 +404,12 @@ __global__ __launch_bounds__(kGT) void k_pipe_band(const PipeArgs a) {
             if (64 * (e + 1) <= PAD) {
               g_traj_store(rec + idx, slot[idx]);
             } else if (idx < TS) {
-              // one LDS read per lane (ye, or rden / beta where the pivot wave latched them), then two register
-              // selects for innov and active: values of this wave, so no hand-off between lanes is involved
+              // one LDS read per lane (the tail of ye), then register selects for the four scalars: values of this
+              // wave, so no hand-off between lanes is involved
               const int sj = idx - PAD;
-              const int off = (sj < 0) ? (int)(slot - lds) + idx : (int)(s_sc - lds) + st * kScStride + (sj < 1 ? 0 : 1);
-              double v = lds[off];
+              double v = slot[sj < 0 ? idx : 0];
+              v = (sj == 0) ? rden : v;
+              v = (sj == 1) ? beta_k : v;
               v = (sj == 2) ? innov : v;
               v = (sj >= 3) ? actv : v;
               g_traj_store(rec + idx, v);
@@ -362,8 +423,8 @@ __global__ __launch_bounds__(kGT) void k_pipe_band(const PipeArgs a) {
       if (!failed && f_ob) {
         const long f = own0 + lane;
         const double2 gk = s_gk[lane * kRowsWG + lane];                        // G_kk, kb_k at the ob's own step
-        const double2 rb = *reinterpret_cast<const double2*>(s_sc + (size_t)lane * kScStride);  // rden, beta
-        const double var = s_var[lane];
+        const double2 rb = make_double2(l_rd, l_be);                           // rden, beta
+        const double var = l_var;
         const bool act = ((asm_mask >> lane) & 1) != 0;
         const double innov = val_l - l_xm;                                     // :85
         a.prior_mean[f] = l_xm;                                                // :66
@@ -400,7 +461,6 @@ __global__ __launch_bounds__(kGT) void k_pipe_band(const PipeArgs a) {
     const bool pre_ob = lane < nb;
     const double pre_err = (wave == kVW && pre_ob) ? a.ob_error[own0 + lane] : 1.0;
     const bool pre_asm = (wave == kVW && pre_ob) ? (a.ob_assim[own0 + lane] != 0) : false;
-    const double pre_sq = sqrt(pre_err);
     if (GC) {  // the three waves that only wait here fetch the block's corner of the obs-obs taper table (ensrf.py:99-115 on the obs rows)
       for (int i = (wave - kVW) * 64 + lane; i < kRowsWG * kRowsWG; i += 3 * 64) {
         const long kg = own0 + (i >> 6), rg = own0 + (i & 63);
@@ -417,35 +477,65 @@ __global__ __launch_bounds__(kGT) void k_pipe_band(const PipeArgs a) {
       // ob's lane (v_readlane), the band's later rows are downdated in registers, nothing is read from LDS
       // inside a band, and the step's record is written at its end.  Gain chain as in efa_pipeline_gram.hip:
       //   kdenom -> q0 = rsq(kdenom) -> { Newton step of q  ||  beta0 = 1/(1 + sqrt(err) q0) } -> beta
-      double mu = pm[lane];
       const bool my_asm = pre_asm;
-      const double err_l = pre_err, sq_l = pre_sq;
       const u64 asm_mask = __ballot(my_asm);
       // cancellation guard: an assimilated pivot whose G_kk fell below 1e-3 of its value at block start; accumulated
       // in the loop, acted upon after the block (a tripped guard abandons the launch: nothing produced meanwhile is used)
-      double thr = my_asm ? 1e-3 * G_s[lane * kRowsWG + lane] : -1.0;
+      const double gjj0 = G_s[lane * kRowsWG + lane];
+      double thr = my_asm ? 1e-3 * gjj0 : -1.0;
       u64 bad = 0ull;
       bool ok = true;
+      // np.var re-centres (:69): var = G_kk / M - mean^2.  The rows are mean-removed perturbations (assimilation.py:47, :147):
+      // their means are rounding residue, mean^2 is below half an ulp of both var and kdenom and changes no bit of
+      // either, so the chain does not carry the means.  A block whose pivot rows are NOT centred (mean^2 above 1e-22 of
+      // var or of the error variance; the means of the 64 rows mix with weights kb <= 1 inside the block) is handed to
+      // the vector-chain kernel, which computes np.var as written.
+      {
+        const double mu0 = pm[lane];
+        const double lim = 1e-22 * fmin(pre_err, gjj0 * invM);
+        bad |= __ballot(pre_ob && !(mu0 * mu0 <= lim));
+      }
       double band[kBand];
 #pragma unroll
       for (int s = 0; s < kBand; ++s) band[s] = G_s[s * kRowsWG + lane];
       // Every value that came from LDS is pinned HERE: the compiler waits for a load where its result is first used;
       // left inside the step code such a wait would be executed every step.
 #define EFA_PIN_BAND(a) _Pragma("unroll") for (int pin_i = 0; pin_i < kBand; ++pin_i) asm volatile("" : "+v"(a[pin_i]))
-      asm volatile("" : "+v"(mu), "+v"(thr));
+      asm volatile("" : "+v"(thr));
       EFA_PIN_BAND(band);
-      double l_rd = 0.0, l_be = 0.0, l_var = 0.0;  // this lane's ob: 1/kdenom, beta, prior variance (latched at its step)
+      // {error, sqrt(error)} of the band's four obs: wave-uniform loads one band ahead (no v_readlane on the chain)
+      const double* ecp = a.ob_errsq + 2 * own0;
+      double ec_nx[kBand][2];
+#pragma unroll
+      for (int s = 0; s < kBand; ++s) {
+        const int o = (s < nb) ? s : 0;
+        ec_nx[s][0] = ecp[2 * o];
+        ec_nx[s][1] = ecp[2 * o + 1];
+      }
       double gprev[kBand - kEarly], gamprev[kBand - kEarly];  // rows and gammas of the previous band's late steps
       double kbprev[kBand - kEarly], tprev[kBand - kEarly];   // GC: their gains kb_j and t_j = G_kj - kb_j G_kk
 #pragma unroll
       for (int o = 0; o < kBand - kEarly; ++o) gprev[o] = gamprev[o] = kbprev[o] = tprev[o] = 0.0;
       EFA_BLOCKSTAMP(lane == 0, 0);
       EFA_WAIT_OUT(lane == 0, 5, 5, __builtin_amdgcn_s_memrealtime());
+      EFA_PS(u64 ps_wait = 0; const u64 ps_t0 = EFA_PS_NOW();)
       for (int b = 0; b < nbands && ok; ++b) {
         const int r0 = kBand * b;
         const int s1 = (nb - r0 < kBand) ? nb - r0 : kBand;  // steps of this band
+        double ec[kBand][2];
+#pragma unroll
+        for (int s = 0; s < kBand; ++s) {
+          ec[s][0] = ec_nx[s][0];
+          ec[s][1] = ec_nx[s][1];
+          const int o = (r0 + kBand + s < nb) ? r0 + kBand + s : 0;
+          ec_nx[s][0] = ecp[2 * o];
+          ec_nx[s][1] = ecp[2 * o + 1];
+        }
         if (b > 0) {  // the band's rows, current through the previous band, from the two G waves
-          if (!EFA_EXP(2048)) ok = wait_gt(&ctl[cBandH], b - 1, false) && wait_gt(&ctl[cBandH + 1], b - 1, false);
+          EFA_PS(const u64 ps_a = EFA_PS_NOW();)
+          if (!EFA_EXP(2048)) ok = wait_gt2(&ctl[cBandH], b - 1);
+          EFA_PS(const u64 ps_r = EFA_PS_NOW(); ps_wait += ps_r - ps_a;
+                 if (a.dbg != nullptr && lane == 0 && own0 + 64 + b < P) { a.dbg[(size_t)(own0 + 64 + b) * 8 + 1] = ps_a; a.dbg[(size_t)(own0 + 64 + b) * 8 + 2] = ps_r; })
           if (!ok) break;
 #pragma unroll
           for (int s = 0; s < kBand; ++s) band[s] = G_s[(r0 + s) * kRowsWG + lane];
@@ -461,7 +551,7 @@ __global__ __launch_bounds__(kGT) void k_pipe_band(const PipeArgs a) {
                 band[s2] = __builtin_fma(-gi, kbprev[o], band[s2]);
                 band[s2] = __builtin_fma(-rl(kbprev[o], r0 + s2), tprev[o], band[s2]);
               } else {
-                band[s2] = __builtin_fma(-(gamprev[o] * gi), gprev[o], band[s2]);
+                band[s2] = __builtin_fma(-gi, gamprev[o], band[s2]);  // gamprev holds the VECTOR gamma g: one product per step, not per row
               }
             }
           }
@@ -482,31 +572,20 @@ __global__ __launch_bounds__(kGT) void k_pipe_band(const PipeArgs a) {
             const double g = band[s];
             const bool act = ((asm_mask >> kk) & 1) != 0;
             bad |= __ballot(!(g > thr)) & (1ull << kk);
-            const double Gkk = rl(g, kk), muk = rl(mu, kk);
-            const double errk = rl(err_l, kk), sqk = rl(sq_l, kk);
-            const double mu2 = muk * muk;
-            const double kdenom = __builtin_fma(Gkk, invM, errk - mu2);   // var + err  (:69, :91)
-            const double q0 = __builtin_amdgcn_rsq(kdenom);
-            const double e = __builtin_fma(-kdenom * q0, q0, 1.0);
-            const double d = e * __builtin_fma(0.375, e, 0.5);            // q = q0 (1 + d)
-            const double q = __builtin_fma(q0, d, q0);
-            const double rden = q * q;                                    // 1 / kdenom
-            const double sq0 = sqk * q0;
-            const double b0 = 1.0 + sq0;
-            const double r0c = __builtin_amdgcn_rcp(b0);
-            const double eb = __builtin_fma(-b0, r0c, 1.0);
-            const double beta0 = __builtin_fma(r0c, __builtin_fma(eb, eb, eb), r0c);
-            const double beta = __builtin_fma(-((beta0 * beta0) * sq0), d, beta0);  // 1 / (1 + sqrt(err / kdenom))  (:135)
+            const double Gkk = rl(g, kk);
+            double rden, beta;
+            gain_scalars(Gkk, invM, ec[s][0], ec[s][1], rden, beta);
+            rden = act ? rden : 0.0;                                      // :74: an ob that is not assimilated changes nothing
             double kc = g * rM1;                                          // :95
             if (GC) kc = tw4[s] * kc;                                     // :115
-            const double km = act ? kc * rden : 0.0;                      // :119
+            const double km = kc * rden;                                  // :119
             const double kb = beta * km;                                  // :136
-            mu = __builtin_fma(-kb, muk, mu);
             // this step's rank-one downdate of G is gamma g g^T, gamma = c (2 - c G_kk) with c = kb_j / G_kj: the form
             // the band's later rows (and L, below) use -- one v_readlane pair per row instead of two
-            const double cc = act ? (beta * rden) * rM1 : 0.0;
+            const double cc = (beta * rden) * rM1;
             const double gam = cc * __builtin_fma(-cc, Gkk, 2.0);
             const double tj = GC ? __builtin_fma(-kb, Gkk, g) : 0.0;      // t_j = G_kj - kb_j G_kk
+            const double gg = gam * g;                                    // the step's downdate of row i is G_ki (gamma g)
 #pragma unroll
             for (int s2 = s + 1; s2 < kBand; ++s2) {
               const double gi = rl(g, r0 + s2);                           // G_k,i of row i = r0 + s2
@@ -516,19 +595,16 @@ __global__ __launch_bounds__(kGT) void k_pipe_band(const PipeArgs a) {
                 band[s2] = __builtin_fma(-kbi, tj, band[s2]);
                 linv[s2] = __builtin_fma(-kbi, linv[s], linv[s2]);        // L[s2][s] = kb_i
               } else {
-                band[s2] = __builtin_fma(-(gam * gi), g, band[s2]);
+                band[s2] = __builtin_fma(-gi, gg, band[s2]);
                 linv[s2] = __builtin_fma(-(cc * gi), linv[s], linv[s2]);  // L[s2][s] = kb_i = c G_k,i
               }
             }
-            const bool mine = lane == kk;
-            l_rd = mine ? rden : l_rd;
-            l_be = mine ? beta : l_be;
-            l_var = mine ? __builtin_fma(Gkk, invM, -mu2) : l_var;        // np.var, ddof = 0 (:69, :70)
             s_gk[kk * kRowsWG + lane] = make_double2(g, kb);              // the step's record: {G_kj, kb_j} per row
             if (s == kEarly - 1 && lane == 0) g_ctl_set(&ctl[cHalf], 2 * b + 1);  // the G waves may start on the next band's rows
+            EFA_PS(if (s == kEarly - 1 && a.dbg != nullptr && lane == 0 && own0 + 64 + b < P) a.dbg[(size_t)(own0 + 64 + b) * 8 + 0] = EFA_PS_NOW();)
             if (s >= kEarly) {
               gprev[s - kEarly] = g;
-              gamprev[s - kEarly] = gam;
+              gamprev[s - kEarly] = gg;
               if (GC) {
                 kbprev[s - kEarly] = kb;
                 tprev[s - kEarly] = tj;
@@ -536,9 +612,7 @@ __global__ __launch_bounds__(kGT) void k_pipe_band(const PipeArgs a) {
             }
           }
         }
-        // per band: the latched scalars of the obs done so far, L^-1 (LinvA[b][t][s], zero where s < t or s >= 8), flags
-        *reinterpret_cast<double2*>(s_sc + (size_t)lane * kScStride) = make_double2(l_rd, l_be);
-        s_var[lane] = l_var;
+        // per band: L^-1 (LinvA[b][t][s], zero where s < t or s >= 8), flags
         if (lane < kBand) {
           double* dst = LinvA + ((size_t)b * kBand + lane) * kBand;
 #pragma unroll
@@ -549,7 +623,13 @@ __global__ __launch_bounds__(kGT) void k_pipe_band(const PipeArgs a) {
           g_ctl_set(&ctl[cLinv], b + 1);
         }
       }
-      if (ok && bad != 0ull) {  // the downdate may have cancelled: abandon the launch (status[2]: the host re-runs
+      EFA_PS(if (a.dbg != nullptr && lane == 0) {
+        a.dbg[(size_t)own0 * 8 + 0] = EFA_PS_NOW() - ps_t0;
+        a.dbg[(size_t)own0 * 8 + 1] = ps_wait;
+      })
+      // (not when the launch is being abandoned anyway: then this block may have run on rows that were never parked)
+      if (ok && bad != 0ull && g_ctl(&ctl[cBail]) == 0 &&
+          __hip_atomic_load(a.status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0) {  // the downdate may have cancelled: abandon the launch (status[2]: the host re-runs
         if (lane == 0) {        // Phase A with the vector-chain kernel)
           give_up();
           __hip_atomic_store(a.status + 2, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -574,82 +654,133 @@ __global__ __launch_bounds__(kGT) void k_pipe_band(const PipeArgs a) {
       for (int jj = 0; jj < 2; ++jj)
 #pragma unroll
         for (int v = 0; v < 4; ++v) acc[I][jj][v] = G_s[(16 * I + 4 * v + lr) * kRowsWG + 16 * (2 * h + jj) + lc];
+    EFA_PS(u64 ps_w1 = 0; u64 ps_p1 = 0; u64 ps_w2 = 0; u64 ps_p2 = 0; u64 ps_l1 = 0;)
+    // From the records {G_kj, kb_j} alone: G_ij -= kb_j G_ki + kb_i (G_kj - kb_j G_kk), two products per K slice of
+    // four steps: (A1 = -G_ki, B1 = kb_j) and (A2 = -kb_i, B2 = t_j).  Steps outside [lo, hi) of the band are masked.
+    // Without localisation kb_j = c G_kj for every row, and the two terms collapse into ONE product per K slice:
+    // G_ij -= gamma G_ki G_kj, gamma = c (2 - c G_kk), c = kb_k / G_kk from the step's own diagonal record.
+    double b1[kBand / 4][2], b2[kBand / 4][2];
+    auto load_b = [&](int r0, int lo, int hi) {
+#pragma unroll
+      for (int q = 0; q < kBand / 4; ++q) {
+        const int sb = 4 * q + lr;                            // this lane's K slot: step r0 + sb
+        const bool on = sb >= lo && sb < hi;
+        const int st = r0 + (on ? sb : 0);
+        const double2 dg = s_gk[st * kRowsWG + st];           // G_kk, kb_k
+        const double Gkk = dg.x;
+        double gam = 0.0;
+        if (!GC) {
+          const double cc = (Gkk > 0.0) ? dg.y * g_rcp(Gkk) : 0.0;  // kb_k = 0 for an ob that is not assimilated
+          gam = cc * __builtin_fma(-cc, Gkk, 2.0);
+        }
+#pragma unroll
+        for (int jj = 0; jj < 2; ++jj) {
+          const double2 r = s_gk[st * kRowsWG + 16 * (2 * h + jj) + lc];
+          if (GC) {
+            b1[q][jj] = on ? r.y : 0.0;
+            b2[q][jj] = on ? __builtin_fma(-r.y, Gkk, r.x) : 0.0;
+          } else {
+            b1[q][jj] = on ? gam * r.x : 0.0;
+            b2[q][jj] = 0.0;
+          }
+        }
+      }
+    };
+    auto update_row = [&](auto Itag, int r0, int lo, int hi) {
+      constexpr int I = decltype(Itag)::value;
+#pragma unroll
+      for (int q = 0; q < kBand / 4; ++q) {
+        const int sb = 4 * q + lr;
+        const bool on = sb >= lo && sb < hi;
+        const double2 r = s_gk[(r0 + (on ? sb : 0)) * kRowsWG + 16 * I + lc];  // A[i = lc][s = lr]
+        const double a1 = on ? -r.x : 0.0, a2 = on ? -r.y : 0.0;
+#pragma unroll
+        for (int jj = 0; jj < 2; ++jj) {
+          acc[I][jj] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b1[q][jj], acc[I][jj], 0, 0, 0);
+          if (GC) acc[I][jj] = __builtin_amdgcn_mfma_f64_16x16x4f64(a2, b2[q][jj], acc[I][jj], 0, 0, 0);
+        }
+      }
+    };
+    auto hand_over = [&](auto Itag, int r0) {  // the next band's rows of tile row I (register v0) back to G_s
+      constexpr int I = decltype(Itag)::value;
+      const int v0 = ((r0 + kBand) & 15) >> 2;
+#pragma unroll
+      for (int jj = 0; jj < 2; ++jj) {
+#pragma unroll
+        for (int vv = 0; vv < kBand / 4; ++vv) {
+          const int v = v0 + vv;
+          const double val = (v == 0) ? acc[I][jj][0] : (v == 1) ? acc[I][jj][1] : (v == 2) ? acc[I][jj][2] : acc[I][jj][3];
+          G_s[(size_t)(16 * I + 4 * v + lr) * kRowsWG + 16 * (2 * h + jj) + lc] = val;
+        }
+      }
+    };
+    // the whole of band bb for the tile rows BELOW the one that holds the band after it: nobody needs them before the
+    // pivot reaches that tile row, so this runs where the G wave would otherwise wait for the pivot
+    auto trailing = [&](int bb) {
+      const int r0 = kBand * bb;
+      const int In = (r0 + kBand) >> 4;
+      if (In >= 3) return;
+      load_b(r0, 0, kBand);
+      if (In < 1) update_row(std::integral_constant<int, 1>(), r0, 0, kBand);
+      if (In < 2) update_row(std::integral_constant<int, 2>(), r0, 0, kBand);
+      update_row(std::integral_constant<int, 3>(), r0, 0, kBand);
+    };
+    int pending = -1;  // a band whose trailing update is still owed
     for (int b = 0; b + 1 < nbands; ++b) {  // nothing follows the last band (a band before the last one is always full)
       const int r0 = kBand * b;
       const int Inext = (r0 + kBand) >> 4;  // tile row of the next band
-      // From the records {G_kj, kb_j} alone: G_ij -= kb_j G_ki + kb_i (G_kj - kb_j G_kk), two products per K slice of
-      // four steps: (A1 = -G_ki, B1 = kb_j) and (A2 = -kb_i, B2 = t_j).  Steps outside [lo, hi) of the band are masked.
-      double b1[kBand / 4][2], b2[kBand / 4][2];
-      auto load_b = [&](int lo, int hi) {
-#pragma unroll
-        for (int q = 0; q < kBand / 4; ++q) {
-          const int sb = 4 * q + lr;                            // this lane's K slot: step r0 + sb
-          const bool on = sb >= lo && sb < hi;
-          const int st = r0 + (on ? sb : 0);
-          const double Gkk = s_gk[st * kRowsWG + st].x;
-#pragma unroll
-          for (int jj = 0; jj < 2; ++jj) {
-            const double2 r = s_gk[st * kRowsWG + 16 * (2 * h + jj) + lc];
-            b1[q][jj] = on ? r.y : 0.0;
-            b2[q][jj] = on ? __builtin_fma(-r.y, Gkk, r.x) : 0.0;
-          }
-        }
-      };
-      auto update_row = [&](auto Itag, int lo, int hi) {
-        constexpr int I = decltype(Itag)::value;
-#pragma unroll
-        for (int q = 0; q < kBand / 4; ++q) {
-          const int sb = 4 * q + lr;
-          const bool on = sb >= lo && sb < hi;
-          const double2 r = s_gk[(r0 + (on ? sb : 0)) * kRowsWG + 16 * I + lc];  // A[i = lc][s = lr]
-          const double a1 = on ? -r.x : 0.0, a2 = on ? -r.y : 0.0;
-#pragma unroll
-          for (int jj = 0; jj < 2; ++jj) {
-            acc[I][jj] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b1[q][jj], acc[I][jj], 0, 0, 0);
-            acc[I][jj] = __builtin_amdgcn_mfma_f64_16x16x4f64(a2, b2[q][jj], acc[I][jj], 0, 0, 0);
-          }
-        }
-      };
-      auto hand_over = [&](auto Itag) {  // the next band's rows of tile row I (registers v0 .. v0 + kBand/4 - 1) back to G_s
-        constexpr int I = decltype(Itag)::value;
-        const int v0 = ((r0 + kBand) & 15) >> 2;
-#pragma unroll
-        for (int jj = 0; jj < 2; ++jj) {
-#pragma unroll
-          for (int vv = 0; vv < kBand / 4; ++vv) {
-            const int v = v0 + vv;
-            const double val = (v == 0) ? acc[I][jj][0] : (v == 1) ? acc[I][jj][1] : (v == 2) ? acc[I][jj][2] : acc[I][jj][3];
-            G_s[(size_t)(16 * I + 4 * v + lr) * kRowsWG + 16 * (2 * h + jj) + lc] = val;
-          }
-        }
-      };
+      // The tile row of the next band must be current through the previous band before this band's early steps go on
+      // top: it is, unless the next band opens a new tile row -- then the owed trailing update comes first.
+      if (pending >= 0 && Inext != ((kBand * pending + kBand) >> 4)) {
+        trailing(pending);
+        pending = -1;
+      }
       // phase 1, as soon as the band's first kEarly steps are published: those steps applied to the tile row of the
       // NEXT band, whose rows go back to the pivot wave at once (it applies the band's other steps itself)
+      EFA_PS(const u64 ps_a = EFA_PS_NOW();)
       if (!wait_gt(&ctl[cHalf], 2 * b, false)) break;
-      load_b(0, kEarly);
+      EFA_PS(const u64 ps_b = EFA_PS_NOW(); ps_w1 += ps_b - ps_a;
+             if (a.dbg != nullptr && lane == 0 && h == 0 && own0 + 64 + b < P) a.dbg[(size_t)(own0 + 64 + b) * 8 + 3] = ps_b;)
+      load_b(r0, 0, kEarly);
+      EFA_PS(asm volatile("" : "+v"(b1[0][0]), "+v"(b1[0][1])); const u64 ps_b2 = EFA_PS_NOW(); ps_l1 += ps_b2 - ps_b;)
       switch (Inext) {
-        case 0: update_row(std::integral_constant<int, 0>(), 0, kEarly); hand_over(std::integral_constant<int, 0>()); break;
-        case 1: update_row(std::integral_constant<int, 1>(), 0, kEarly); hand_over(std::integral_constant<int, 1>()); break;
-        case 2: update_row(std::integral_constant<int, 2>(), 0, kEarly); hand_over(std::integral_constant<int, 2>()); break;
-        default: update_row(std::integral_constant<int, 3>(), 0, kEarly); hand_over(std::integral_constant<int, 3>()); break;
+        case 0: update_row(std::integral_constant<int, 0>(), r0, 0, kEarly); hand_over(std::integral_constant<int, 0>(), r0); break;
+        case 1: update_row(std::integral_constant<int, 1>(), r0, 0, kEarly); hand_over(std::integral_constant<int, 1>(), r0); break;
+        case 2: update_row(std::integral_constant<int, 2>(), r0, 0, kEarly); hand_over(std::integral_constant<int, 2>(), r0); break;
+        default: update_row(std::integral_constant<int, 3>(), r0, 0, kEarly); hand_over(std::integral_constant<int, 3>(), r0); break;
       }
       if (lane == 0) g_ctl_set(&ctl[cBandH + h], b + 1);
-      // phase 2, after the band: its other steps for that tile row, the whole band for the tile rows below it
+      EFA_PS(const u64 ps_c = EFA_PS_NOW(); ps_p1 += ps_c - ps_b;
+             if (a.dbg != nullptr && lane == 0 && h == 0 && own0 + 64 + b < P) a.dbg[(size_t)(own0 + 64 + b) * 8 + 4] = ps_c;)
+      // while the pivot runs the band's other steps: the trailing update owed from the previous band
+      if (pending >= 0) {
+        trailing(pending);
+        pending = -1;
+      }
+      // phase 2, after the band: its other steps for the next band's tile row; the tile rows below it are owed
       if (!wait_gt(&ctl[cSReady], r0 + kBand - 1, false)) break;
-      load_b(kEarly, kBand);
+      EFA_PS(const u64 ps_d = EFA_PS_NOW(); ps_w2 += ps_d - ps_c;)
+      load_b(r0, kEarly, kBand);
       switch (Inext) {
-        case 0: update_row(std::integral_constant<int, 0>(), kEarly, kBand); break;
-        case 1: update_row(std::integral_constant<int, 1>(), kEarly, kBand); break;
-        case 2: update_row(std::integral_constant<int, 2>(), kEarly, kBand); break;
-        default: update_row(std::integral_constant<int, 3>(), kEarly, kBand); break;
+        case 0: update_row(std::integral_constant<int, 0>(), r0, kEarly, kBand); break;
+        case 1: update_row(std::integral_constant<int, 1>(), r0, kEarly, kBand); break;
+        case 2: update_row(std::integral_constant<int, 2>(), r0, kEarly, kBand); break;
+        default: update_row(std::integral_constant<int, 3>(), r0, kEarly, kBand); break;
       }
-      if (Inext < 3) {
-        load_b(0, kBand);
-        if (Inext < 1) update_row(std::integral_constant<int, 1>(), 0, kBand);
-        if (Inext < 2) update_row(std::integral_constant<int, 2>(), 0, kBand);
-        update_row(std::integral_constant<int, 3>(), 0, kBand);
-      }
+#if EFA_G_DEFER
+      pending = (Inext < 3) ? b : -1;
+#else
+      trailing(b);
+#endif
+      EFA_PS(asm volatile("" : "+v"(acc[3][0][0]), "+v"(acc[3][1][0])); ps_p2 += EFA_PS_NOW() - ps_d;)
     }
+    EFA_PS(if (a.dbg != nullptr && lane == 0) {
+      a.dbg[(size_t)own0 * 8 + 2 + 4 * h * 0 + (h ? 8 : 0) + 0] = ps_w1;
+      a.dbg[(size_t)own0 * 8 + 2 + (h ? 8 : 0) + 1] = ps_p1;
+      a.dbg[(size_t)own0 * 8 + 2 + (h ? 8 : 0) + 2] = ps_w2;
+      a.dbg[(size_t)own0 * 8 + 2 + (h ? 8 : 0) + 3] = ps_p2;
+      a.dbg[(size_t)own0 * 8 + 2 + (h ? 8 : 0) + 4] = ps_l1;
+    })
     __syncthreads();  // B3
     return;
   }
@@ -821,6 +952,7 @@ __global__ __launch_bounds__(kGT) void k_pipe_band(const PipeArgs a) {
       s23 = *reinterpret_cast<const double2*>(slot + PAD + 2);  // innov, active
     };
     auto apply = [&](const double (&y)[2 * NC], const double2 s01, const double2 s23, const double w) {
+      if (EFA_EXP(4096)) return;  // timing experiment: followers do no arithmetic
       if (__builtin_amdgcn_readfirstlane((int)(s23.y != 0.0)) != 0) {
         const double dot = group_dot<PLg, NC>(x, y);
         double kc = dot * rM1;                              // :95

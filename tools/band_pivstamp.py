@@ -1,0 +1,48 @@
+"""Where a block's time goes inside the band leader's serial waves: `make -C efa_xray_amd/csrc pivstamp`, then
+EFA_HIP_LIB=efa_xray_amd/libefa_hip_pivstamp.so python tools/band_pivstamp.py [P].
+Per block of 64 obs (medians, shader cycles): the pivot wave's loop, the part of it spent waiting for the G waves'
+rows; per G wave: waiting for the pivot's first two steps of a band, phase 1 (early rows), waiting for the band's end,
+phase 2 (the rest of the band)."""
+import sys, os, ctypes
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+from efa_xray_amd import _lib
+ctx = _lib.get_context(0)
+M = 100
+P = int(sys.argv[1]) if len(sys.argv) > 1 else 10000
+bits = int(sys.argv[2]) if len(sys.argv) > 2 else 0
+rng = np.random.default_rng(0)
+ctx.set_option("path", 2); ctx.set_option("pipeline", 1); ctx.set_option("gram", 2); ctx.set_option("pipe_debug", 4 | bits)
+ctx.set_option("timing", 1)
+HX = rng.standard_normal((P, M)) * 3
+val = HX.mean(axis=1) + rng.standard_normal(P); err = np.ones(P); asm = np.ones(P, bool)
+for _ in range(3):
+    Yp = ctx.to_device(HX); ym = ctx.empty((P,))
+    ctx.form_perts(P, M, Yp, ym, Yp)
+    ctx.obs_phase(M, P, ym, Yp, val, err, asm)
+addr = ctx.get_option("pipe_dbg_addr")
+out = np.zeros((P, 8), dtype=np.uint64)
+_lib._check(ctx.lib, ctx.lib.efa_memcpy_d2h(ctx.handle, out.ctypes.data, ctypes.c_void_p(addr), out.nbytes))
+t = out.astype(np.int64)
+nb = P // 64
+med = lambda f: float(np.median([f(b) for b in range(1, nb)]))
+print("bits %d" % bits, "kind %d obs_ms %.3f" % (ctx.get_option("phase_a_kind"), ctx.last_timing()["obs_ms"]))
+print("pivot loop %.0f cycles per block (%.0f per step), of which waiting for the G waves' rows %.0f"
+      % (med(lambda b: t[64 * b, 0]), med(lambda b: t[64 * b, 0]) / 64, med(lambda b: t[64 * b, 1])))
+for h in (0, 1):
+    r = [med(lambda b, i=i: t[64 * b + h, 2 + i]) for i in range(5)]
+    print("G wave %d per block: wait first half %.0f | phase 1 %.0f (its operand loads %.0f) | wait band end %.0f | phase 2 %.0f  (sum %.0f)"
+          % (h, r[0], r[1], r[4], r[2], r[3], sum(r[:4])))
+# per band (rows own0+64+b of the NEXT block's stamp rows hold band b of block own0): absolute s_memtime stamps
+ev = []
+for blk in range(2, nb - 2):
+    for b in range(1, 15):
+        r = t[64 * blk + 64 + b]
+        rp = t[64 * blk + 64 + b + 1]      # next band: its wait start / rows received
+        # r[0] cHalf set (band b), r[3] G wave saw it, r[4] G wave set the rows flag; rp[1] pivot starts waiting for band b+1's rows, rp[2] got them
+        if r[0] and r[3] and r[4] and rp[1] and rp[2]:
+            ev.append((r[3] - r[0], r[4] - r[3], rp[1] - r[0], rp[2] - r[4], rp[2] - rp[1]))
+ev = np.array(ev)
+print("per band (median cycles): cHalf set -> G wave sees it %.0f | -> rows flag set %.0f | cHalf set -> pivot starts waiting %.0f | flag set -> pivot sees rows %.0f | pivot waits %.0f"
+      % tuple(np.median(ev, axis=0)))
+ctx.set_option("pipe_debug", 0); ctx.set_option("path", 0)
