@@ -62,13 +62,19 @@ static_assert(PLg == 4 && kRowsWG == 64, "layout assumptions of the band kernel"
 static_assert(true, "");
 enum { cReady = 0, cBail = 1, cSReady = 2, cFwd = 3, cProg = 4 /* ..7 */, cBandH = 8 /* ..9 */, cLinv = 10, cPark = 11, cYe = 12, cHalf = 13 };
 #ifndef EFA_EARLY
-#define EFA_EARLY 1
+#define EFA_EARLY 0
 #endif
 #ifndef EFA_G_DEFER
 #define EFA_G_DEFER 0  // 1: the G waves owe a band's trailing update until after the next band's early rows (measured: slower)
 #endif
-constexpr int kEarly = EFA_EARLY;  // steps of a band the G waves have applied to the next band's rows when they hand them over
-static_assert(kEarly >= 1 && kEarly < kBand, "early hand-over");
+// kEarly >= 1: the G waves hand the NEXT band's rows to the pivot wave once kEarly steps of the current band are applied
+//   to them (the pivot applies the band's other steps itself): one pivot -> G wave -> pivot round trip through LDS flags
+//   per band, ~2.4 k cycles, which the band's remaining steps do not cover (profiles/r03_phase_a_pivot_loop.txt).
+// kEarly == 0 (default): the G waves run one whole band behind.  After band b they hand over the rows of band b + 2,
+//   current through band b; the pivot wave, which needs them a full band later, applies band b + 1 to them itself (16 row
+//   updates per band instead of 12).  The round trip has a band's time to complete: the pivot never waits.
+constexpr int kEarly = EFA_EARLY;
+static_assert(kEarly >= 0 && kEarly < kBand, "early hand-over");
 constexpr int kScStride = 4;  // doubles per ob: rden, beta (latched by the pivot wave), innov, active (added by the forwarder): the record's scalars
 
 __device__ __forceinline__ u64 g_traj_load(const u64* p) {
@@ -533,7 +539,7 @@ __global__ __launch_bounds__(kGT) void k_pipe_band(const PipeArgs a) {
         }
         if (b > 0) {  // the band's rows, current through the previous band, from the two G waves
           EFA_PS(const u64 ps_a = EFA_PS_NOW();)
-          if (!EFA_EXP(2048)) ok = wait_gt2(&ctl[cBandH], b - 1);
+          if (!EFA_EXP(2048) && (kEarly > 0 || b >= 2)) ok = wait_gt2(&ctl[cBandH], b - 1);  // kEarly == 0: band 1's rows are the initial ones
           EFA_PS(const u64 ps_r = EFA_PS_NOW(); ps_wait += ps_r - ps_a;
                  if (a.dbg != nullptr && lane == 0 && own0 + 64 + b < P) { a.dbg[(size_t)(own0 + 64 + b) * 8 + 1] = ps_a; a.dbg[(size_t)(own0 + 64 + b) * 8 + 2] = ps_r; })
           if (!ok) break;
@@ -701,9 +707,9 @@ __global__ __launch_bounds__(kGT) void k_pipe_band(const PipeArgs a) {
         }
       }
     };
-    auto hand_over = [&](auto Itag, int r0) {  // the next band's rows of tile row I (register v0) back to G_s
+    auto hand_over = [&](auto Itag, int rnext) {  // the rows rnext .. rnext + 3 of tile row I (register v0) back to G_s
       constexpr int I = decltype(Itag)::value;
-      const int v0 = ((r0 + kBand) & 15) >> 2;
+      const int v0 = (rnext & 15) >> 2;
 #pragma unroll
       for (int jj = 0; jj < 2; ++jj) {
 #pragma unroll
@@ -725,6 +731,27 @@ __global__ __launch_bounds__(kGT) void k_pipe_band(const PipeArgs a) {
       if (In < 2) update_row(std::integral_constant<int, 2>(), r0, 0, kBand);
       update_row(std::integral_constant<int, 3>(), r0, 0, kBand);
     };
+    if (kEarly == 0) {
+      // one band behind: after band b, the rows of band b + 2 first (they go back to the pivot wave), then the tile rows below
+      for (int b = 0; b + 2 < nbands; ++b) {
+        const int r0 = kBand * b;
+        const int I2 = (r0 + 2 * kBand) >> 4;  // tile row of band b + 2
+        if (!wait_gt(&ctl[cSReady], r0 + kBand - 1, false)) break;
+        load_b(r0, 0, kBand);
+        switch (I2) {
+          case 0: update_row(std::integral_constant<int, 0>(), r0, 0, kBand); hand_over(std::integral_constant<int, 0>(), r0 + 2 * kBand); break;
+          case 1: update_row(std::integral_constant<int, 1>(), r0, 0, kBand); hand_over(std::integral_constant<int, 1>(), r0 + 2 * kBand); break;
+          case 2: update_row(std::integral_constant<int, 2>(), r0, 0, kBand); hand_over(std::integral_constant<int, 2>(), r0 + 2 * kBand); break;
+          default: update_row(std::integral_constant<int, 3>(), r0, 0, kBand); hand_over(std::integral_constant<int, 3>(), r0 + 2 * kBand); break;
+        }
+        if (lane == 0) g_ctl_set(&ctl[cBandH + h], b + 2);
+        if (I2 < 1) update_row(std::integral_constant<int, 1>(), r0, 0, kBand);
+        if (I2 < 2) update_row(std::integral_constant<int, 2>(), r0, 0, kBand);
+        if (I2 < 3) update_row(std::integral_constant<int, 3>(), r0, 0, kBand);
+      }
+      __syncthreads();  // B3
+      return;
+    }
     int pending = -1;  // a band whose trailing update is still owed
     for (int b = 0; b + 1 < nbands; ++b) {  // nothing follows the last band (a band before the last one is always full)
       const int r0 = kBand * b;
@@ -744,10 +771,10 @@ __global__ __launch_bounds__(kGT) void k_pipe_band(const PipeArgs a) {
       load_b(r0, 0, kEarly);
       EFA_PS(asm volatile("" : "+v"(b1[0][0]), "+v"(b1[0][1])); const u64 ps_b2 = EFA_PS_NOW(); ps_l1 += ps_b2 - ps_b;)
       switch (Inext) {
-        case 0: update_row(std::integral_constant<int, 0>(), r0, 0, kEarly); hand_over(std::integral_constant<int, 0>(), r0); break;
-        case 1: update_row(std::integral_constant<int, 1>(), r0, 0, kEarly); hand_over(std::integral_constant<int, 1>(), r0); break;
-        case 2: update_row(std::integral_constant<int, 2>(), r0, 0, kEarly); hand_over(std::integral_constant<int, 2>(), r0); break;
-        default: update_row(std::integral_constant<int, 3>(), r0, 0, kEarly); hand_over(std::integral_constant<int, 3>(), r0); break;
+        case 0: update_row(std::integral_constant<int, 0>(), r0, 0, kEarly); hand_over(std::integral_constant<int, 0>(), r0 + kBand); break;
+        case 1: update_row(std::integral_constant<int, 1>(), r0, 0, kEarly); hand_over(std::integral_constant<int, 1>(), r0 + kBand); break;
+        case 2: update_row(std::integral_constant<int, 2>(), r0, 0, kEarly); hand_over(std::integral_constant<int, 2>(), r0 + kBand); break;
+        default: update_row(std::integral_constant<int, 3>(), r0, 0, kEarly); hand_over(std::integral_constant<int, 3>(), r0 + kBand); break;
       }
       if (lane == 0) g_ctl_set(&ctl[cBandH + h], b + 1);
       EFA_PS(const u64 ps_c = EFA_PS_NOW(); ps_p1 += ps_c - ps_b;

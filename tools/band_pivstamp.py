@@ -43,6 +43,7 @@ for blk in range(2, nb - 2):
         if r[0] and r[3] and r[4] and rp[1] and rp[2]:
             ev.append((r[3] - r[0], r[4] - r[3], rp[1] - r[0], rp[2] - r[4], rp[2] - rp[1]))
 ev = np.array(ev)
-print("per band (median cycles): cHalf set -> G wave sees it %.0f | -> rows flag set %.0f | cHalf set -> pivot starts waiting %.0f | flag set -> pivot sees rows %.0f | pivot waits %.0f"
+if len(ev):
+  print("per band (median cycles): cHalf set -> G wave sees it %.0f | -> rows flag set %.0f | cHalf set -> pivot starts waiting %.0f | flag set -> pivot sees rows %.0f | pivot waits %.0f"
       % tuple(np.median(ev, axis=0)))
 ctx.set_option("pipe_debug", 0); ctx.set_option("path", 0)
