@@ -122,6 +122,22 @@ __device__ __forceinline__ void gain_scalars(double Gkk, double invM, double err
   const double beta0 = __builtin_fma(r0c, __builtin_fma(eb, eb, eb), r0c);
   beta = __builtin_fma(-((beta0 * beta0) * sq0), d, beta0);     // 1 / (1 + sqrt(err / kdenom))  (:135)
 }
+// What the serial chain itself needs of an observation is one number, c = beta / ((M-1) kdenom): every gain is
+// kb_j = w_kj c G_kj and the downdate of G is gamma g g^T with gamma = c (2 - c G_kk).  With beta = 1/(1 + sqrt(err/kdenom)),
+//   c = 1 / ((M-1) (kdenom + sqrt(err) sqrt(kdenom))):
+// one rsq with a Newton step for sqrt(kdenom), one rcp with a cubic step -- 12 dependent operations instead of the 20 that
+// form 1/kdenom and beta separately (the forwarder wave still forms those two, off the chain, for the records).
+__device__ __forceinline__ double gain_c(double Gkk, double invM, double errk, double sqk, double rM1) {
+  const double v = __builtin_fma(Gkk, invM, errk);              // kdenom = var + err  (:69, :91)
+  const double q0 = __builtin_amdgcn_rsq(v);
+  const double r0 = v * q0;                                     // ~ sqrt(v)
+  const double er = __builtin_fma(-r0, r0, v);
+  const double r = __builtin_fma(er, 0.5 * q0, r0);             // sqrt(v), one Newton step
+  const double u = __builtin_fma(sqk, r, v);                    // kdenom (1 + sqrt(err / kdenom)) = kdenom / beta
+  const double c0 = __builtin_amdgcn_rcp(u);
+  const double eu = __builtin_fma(-u, c0, 1.0);
+  return __builtin_fma(c0, __builtin_fma(eu, eu, eu), c0) * rM1;
+}
 __device__ __forceinline__ double rl(double v, int lane) {  // value held by `lane` (wave-uniform index)
   const int lo = __builtin_amdgcn_readlane(__double2loint(v), lane);
   const int hi = __builtin_amdgcn_readlane(__double2hiint(v), lane);
@@ -579,16 +595,12 @@ __global__ __launch_bounds__(kGT) void k_pipe_band(const PipeArgs a) {
             const bool act = ((asm_mask >> kk) & 1) != 0;
             bad |= __ballot(!(g > thr)) & (1ull << kk);
             const double Gkk = rl(g, kk);
-            double rden, beta;
-            gain_scalars(Gkk, invM, ec[s][0], ec[s][1], rden, beta);
-            rden = act ? rden : 0.0;                                      // :74: an ob that is not assimilated changes nothing
-            double kc = g * rM1;                                          // :95
-            if (GC) kc = tw4[s] * kc;                                     // :115
-            const double km = kc * rden;                                  // :119
-            const double kb = beta * km;                                  // :136
+            double cc = gain_c(Gkk, invM, ec[s][0], ec[s][1], rM1);       // beta / ((M-1) kdenom)  (:95, :119, :135, :136)
+            cc = act ? cc : 0.0;                                          // :74: an ob that is not assimilated changes nothing
+            double kb = cc * g;                                           // the rows' gains (:136)
+            if (GC) kb = tw4[s] * kb;                                     // :115
             // this step's rank-one downdate of G is gamma g g^T, gamma = c (2 - c G_kk) with c = kb_j / G_kj: the form
             // the band's later rows (and L, below) use -- one v_readlane pair per row instead of two
-            const double cc = (beta * rden) * rM1;
             const double gam = cc * __builtin_fma(-cc, Gkk, 2.0);
             const double tj = GC ? __builtin_fma(-kb, Gkk, g) : 0.0;      // t_j = G_kj - kb_j G_kk
             const double gg = gam * g;                                    // the step's downdate of row i is G_ki (gamma g)
