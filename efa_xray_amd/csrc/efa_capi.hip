@@ -149,6 +149,7 @@ struct efa_ctx {
   DevBuf ob_val, ob_err, ob_asm, ob_lat, ob_lon, ob_hw, ob_errsq;  // device copies [P] ([P][2] the last)
   DevBuf d_prior_mean, d_prior_var, d_post_mean, d_post_var, d_assimilated;
   DevBuf Yw, ymw;  // obs block workspace [(P+M)][M], [(P+M)]
+  DevBuf win_Y, win_m;  // rows of one Phase-A window + the transform rows (only when P exceeds one persistent launch)
   // --- state phase workspaces ---------------------------------------------
   DevBuf W;           // taper table [nb][ncol]
   DevBuf gc_cnt, gc_ub, gc_order, gc_obtrig, gc_off, gc_idx, gc_wts, gc_pairs;  // one-pass GC sweep: CSR active lists
@@ -315,132 +316,40 @@ int obs_phase(efa_ctx* c, int M, long P, double* ym_dev, double* Yp_dev, const d
   EFA_HIP(hipMemcpyAsync(ymw, ym_dev, dP, hipMemcpyDeviceToDevice, s));
   if (carry_T) EFA_HIP(launch_set_identity(M, Yw + (size_t)P * M, ymw + P, s));
 
-  // ---- persistent pipeline (one launch for all P obs) ---------------------------------
-  bool done_by_pipeline = false;
-  const bool tw_fits = (loc_mode != EFA_LOC_GC) || ((size_t)P * (size_t)R * sizeof(double) <= ((size_t)3 << 30));
-  if (c->use_pipeline && pipeline_supported(M, R) && tw_fits) {
-    // the band kernel pads a record's ye row to its own lane layout: buffers are sized for the longer record
-    const long TS_std = traj_stride(M), TS_band = band_traj_stride(M);
-    const long TS = TS_std > TS_band ? TS_std : TS_band;
+  // ---- Phase A in WINDOWS of observations -----------------------------------------------------------------
+  // A persistent launch keeps 64 obs rows per workgroup and needs its whole grid resident: at most kPipeMaxWGs * 64
+  // rows (the window's obs + the M carried transform rows).  More observations are taken window by window: the
+  // window's rows and the transform rows go through one persistent launch (in a workspace when the window is not the
+  // whole block), and the rows of all OTHER observations -- earlier windows' (the reference keeps updating them,
+  // ensrf.py:141 acts on every augmented row) and later ones' -- take the window's trajectory through the per-batch
+  // sweep kernel, 64 obs per pass.  A window whose launch gives up (bounded spin, cancellation guard twice) is redone,
+  // for its own observations only, by the per-batch kernels.
+  // Without localisation a window that is not the whole block carries a SECOND set of identity rows: they come out as the
+  // window's own transform (T_w, w_w), which then updates all other rows of the block in one k_transform pass instead of
+  // one sweep pass per 64 obs.
+  const long Wone = (long)kPipeMaxWGs * kPipeRowsPerWG - extra;            // one window covers the block up to here
+  const long Wmax = (P <= Wone) ? Wone : Wone - extra;                       // else: two sets of extra rows per window
+  const bool pipe_ok = c->use_pipeline && Wmax > 0 && pipeline_supported(M, (P <= Wone ? P + extra : Wmax + 2 * extra));
+  const long TS_std = traj_stride(M), TS_band = band_traj_stride(M);
+  const long TS = TS_std > TS_band ? TS_std : TS_band;
+  const long B = effective_batch(c, M);
+  bool traj_kind_band = false, any_pipeline = false, any_batch = false;
+  if (pipe_ok) {
     EFA_TRY(c->traj.reserve((size_t)P * TS * sizeof(unsigned long long)));
     EFA_TRY(c->status.reserve(3 * sizeof(int)));
     EFA_HIP(launch_fill_u64(c->traj.as<unsigned long long>(), (size_t)P * TS, kTrajSentinel, s));
-    EFA_HIP(hipMemsetAsync(c->status.p, 0, 3 * sizeof(int), s));
-    PipeArgs pa{};
-    pa.Yp = Yw;
-    pa.ym = ymw;
-    pa.R = R;
-    pa.P = P;
-    pa.M = M;
-    pa.ob_value = c->ob_val.as<double>();
-    pa.ob_error = c->ob_err.as<double>();
-    pa.ob_assim = c->ob_asm.as<uint8_t>();
-    pa.ob_errsq = c->ob_errsq.as<double>();
-    pa.loc_mode = loc_mode;
-    pa.tw = nullptr;
-    if (loc_mode == EFA_LOC_GC) {
-      EFA_TRY(c->tw_mat.reserve((size_t)P * R * sizeof(double)));
-      EFA_TRY(c->gc_obtrig.reserve((size_t)P * 6 * sizeof(double)));
-      EFA_HIP(launch_obs_taper_matrix(P, R, c->ob_lat.as<double>(), c->ob_lon.as<double>(), c->ob_hw.as<double>(), c->gc_obtrig.as<double>(),
-                                      c->tw_mat.as<double>(), s));
-      pa.tw = c->tw_mat.as<double>();
-    }
-    pa.traj = c->traj.as<unsigned long long>();
-    pa.coef = c->coef.as<double>();
-    pa.prior_mean = c->d_prior_mean.as<double>();
-    pa.prior_var = c->d_prior_var.as<double>();
-    pa.post_mean = c->d_post_mean.as<double>();
-    pa.post_var = c->d_post_var.as<double>();
-    pa.assimilated = c->d_assimilated.as<uint8_t>();
-    pa.status = c->status.as<int>();
-    pa.spin_limit = c->spin_limit;
-    pa.spin_ticks = (c->spin_ms >= 0 ? c->spin_ms : 100 + P / 100) * 100000L;  // s_memrealtime runs at 100 MHz
-    pa.cu_count = c->cu_count;
-    pa.debug = (int)c->pipe_debug;
-    pa.dbg = nullptr;
-    if (c->pipe_debug & 4) {
-      EFA_TRY(c->dbg.reserve((size_t)P * 8 * sizeof(unsigned long long)));
-      EFA_HIP(hipMemsetAsync(c->dbg.p, 0, (size_t)P * 8 * sizeof(unsigned long long), s));
-      pa.dbg = c->dbg.as<unsigned long long>();
-    }
-    // attempt 0: Gram-space leader (option "gram"); attempt 1: vector-chain pipeline.  A failed
-    // attempt (bounded spin expired, or the Gram downdate's cancellation guard) may have let
-    // finished workgroups write their rows back, so the obs block is restored before the next.
-    // An attempt is skipped when its grid cannot be co-resident (occupancy query in the launcher), and after an
-    // attempt whose bounded spins EXPIRED (status 1: some workgroups never became resident, e.g. another
-    // kernel holds CUs) the other persistent kernel is not tried either: it has the same residency need.
-    const int first_kind = (c->use_gram >= 2 && pipeline_band_supported(M, R, loc_mode)) ? 4
-                           : (c->use_gram >= 1 && pipeline_gram_supported(M, R, loc_mode)) ? 3 : 1;
-    for (int attempt = (first_kind == 1) ? 1 : 0; attempt < 2 && !done_by_pipeline; ++attempt) {
-      const int kind = (attempt == 0) ? first_kind : 1;
-      const hipError_t le = kind == 4 ? launch_pipeline_band(pa, s) : kind == 3 ? launch_pipeline_gram(pa, s) : launch_pipeline(pa, s);
-      if (le == hipErrorCooperativeLaunchTooLarge) {
-        (void)hipGetLastError();
-        continue;
-      }
-      EFA_HIP(le);
-      int st[3] = {0, 0, 0};
-      EFA_HIP(hipMemcpyAsync(st, c->status.p, sizeof(st), hipMemcpyDeviceToHost, s));
-      EFA_HIP(hipStreamSynchronize(s));
-      if (st[0] == 0 && st[1] == 0) {
-        done_by_pipeline = true;
-        c->ye_ptr = reinterpret_cast<const double*>(c->traj.p);
-        c->ye_stride = (kind == 4) ? TS_band : TS_std;
-        c->phase_a_kind = kind;
-      } else {
-        EFA_HIP(hipMemcpyAsync(Yw, Yp_dev, (size_t)P * M * sizeof(double), hipMemcpyDeviceToDevice, s));
-        EFA_HIP(hipMemcpyAsync(ymw, ym_dev, dP, hipMemcpyDeviceToDevice, s));
-        if (carry_T) EFA_HIP(launch_set_identity(M, Yw + (size_t)P * M, ymw + P, s));
-        if (st[2] == 0) break;  // not the Gram guard, so a spin expired: straight to the per-batch kernels
-        if (attempt == 0) {
-          EFA_HIP(launch_fill_u64(c->traj.as<unsigned long long>(), (size_t)P * TS, kTrajSentinel, s));
-          EFA_HIP(hipMemsetAsync(c->status.p, 0, 3 * sizeof(int), s));
-        }
-      }
-    }
   }
-  if (!done_by_pipeline) {
-    c->ye_ptr = c->Ye_rec.as<double>();
-    c->ye_stride = M;
-    c->phase_a_kind = 2;
-  }
-  const long B = effective_batch(c, M);
-  for (long b0 = 0; !done_by_pipeline && b0 < P; b0 += B) {
-    const int nb = (int)((P - b0 < B) ? (P - b0) : B);
-    DiagArgs d{};
-    d.Yp = Yw;
-    d.ym = ymw;
-    d.M = M;
-    d.b0 = b0;
-    d.nb = nb;
-    d.ob_value = c->ob_val.as<double>();
-    d.ob_error = c->ob_err.as<double>();
-    d.ob_assim = c->ob_asm.as<uint8_t>();
-    d.loc_mode = loc_mode;
-    d.ob_lat = c->ob_lat.as<double>();
-    d.ob_lon = c->ob_lon.as<double>();
-    d.ob_hw = c->ob_hw.as<double>();
-    d.Ye_rec = c->Ye_rec.as<double>();
-    d.coef = c->coef.as<double>();
-    d.prior_mean = c->d_prior_mean.as<double>();
-    d.prior_var = c->d_prior_var.as<double>();
-    d.post_mean = c->d_post_mean.as<double>();
-    d.post_var = c->d_post_var.as<double>();
-    d.assimilated = c->d_assimilated.as<uint8_t>();
-    EFA_HIP(launch_diag(d, s));
-
-    long act = 0;
-    for (int k = 0; k < nb; ++k) act += ob_assim[b0 + k] ? 1 : 0;
-    if (act == 0 || R == nb) continue;
+  // rows [lo, hi) of the obs block take obs [b0, b0 + nb) from (Ye, ye_stride): the per-batch sweep
+  auto sweep_rows = [&](long b0, int nb, const double* Ye, long ye_stride, long skip_lo, long skip_hi, long nrows) -> int {
     SweepArgs a{};
     a.Xin = Yw;
     a.xin = ymw;
     a.Xout = Yw;
     a.xout = ymw;
-    a.nrows = R;
+    a.nrows = nrows;
     a.M = M;
-    a.Ye = c->Ye_rec.as<double>() + (size_t)b0 * M;
-    a.ye_stride = M;
+    a.Ye = Ye;
+    a.ye_stride = ye_stride;
     a.coef = c->coef.as<double>() + (size_t)b0 * kCoefStride;
     a.nb = nb;
     a.taper_mode = (loc_mode == EFA_LOC_GC) ? kTaperObs : kTaperNone;
@@ -449,10 +358,218 @@ int obs_phase(efa_ctx* c, int M, long P, double* ym_dev, double* Yp_dev, const d
     a.ob_lat = c->ob_lat.as<double>() + b0;
     a.ob_lon = c->ob_lon.as<double>() + b0;
     a.ob_hw = c->ob_hw.as<double>() + b0;
-    a.skip_lo = b0;
-    a.skip_hi = b0 + nb;
+    a.skip_lo = skip_lo;
+    a.skip_hi = skip_hi;
     a.taper_rows = P;
     EFA_HIP(launch_sweep(a, s));
+    return EFA_OK;
+  };
+  // obs [w0, w1) by the per-batch kernels (k_diag on the batch's own rows, k_sweep on every other row of the block)
+  auto batch_window = [&](long w0, long w1) -> int {
+    for (long b0 = w0; b0 < w1; b0 += B) {
+      const int nb = (int)((w1 - b0 < B) ? (w1 - b0) : B);
+      DiagArgs d{};
+      d.Yp = Yw;
+      d.ym = ymw;
+      d.M = M;
+      d.b0 = b0;
+      d.nb = nb;
+      d.ob_value = c->ob_val.as<double>();
+      d.ob_error = c->ob_err.as<double>();
+      d.ob_assim = c->ob_asm.as<uint8_t>();
+      d.loc_mode = loc_mode;
+      d.ob_lat = c->ob_lat.as<double>();
+      d.ob_lon = c->ob_lon.as<double>();
+      d.ob_hw = c->ob_hw.as<double>();
+      d.Ye_rec = c->Ye_rec.as<double>();
+      d.coef = c->coef.as<double>();
+      d.prior_mean = c->d_prior_mean.as<double>();
+      d.prior_var = c->d_prior_var.as<double>();
+      d.post_mean = c->d_post_mean.as<double>();
+      d.post_var = c->d_post_var.as<double>();
+      d.assimilated = c->d_assimilated.as<uint8_t>();
+      EFA_HIP(launch_diag(d, s));
+      long act = 0;
+      for (int k = 0; k < nb; ++k) act += ob_assim[b0 + k] ? 1 : 0;
+      if (act == 0 || R == nb) continue;
+      EFA_TRY(sweep_rows(b0, nb, c->Ye_rec.as<double>() + (size_t)b0 * M, M, b0, b0 + nb, R));
+    }
+    return EFA_OK;
+  };
+  const long nwin = pipe_ok ? (P + Wmax - 1) / Wmax : 1;
+  for (long w = 0; w < nwin; ++w) {
+    const long w0 = pipe_ok ? w * Wmax : 0, w1 = pipe_ok ? ((w0 + Wmax < P) ? w0 + Wmax : P) : P;
+    const long Pw = w1 - w0, Rw = Pw + ((nwin == 1) ? extra : 2 * extra);
+    bool done = false;
+    const bool tw_fits = (loc_mode != EFA_LOC_GC) || ((size_t)Pw * (size_t)Rw * sizeof(double) <= ((size_t)3 << 30));
+    if (pipe_ok && tw_fits) {
+      // the launch's rows: the block itself when one window covers it, else a workspace [window rows | transform rows]
+      const bool direct = (nwin == 1);
+      double* Wy = Yw;
+      double* Wm = ymw;
+      if (!direct) {
+        EFA_TRY(c->win_Y.reserve((size_t)Rw * M * sizeof(double)));
+        EFA_TRY(c->win_m.reserve((size_t)Rw * sizeof(double)));
+        Wy = c->win_Y.as<double>();
+        Wm = c->win_m.as<double>();
+      }
+      auto stage_in = [&]() -> int {  // (also the restore after a failed attempt: the block keeps the pre-launch rows)
+        if (direct) return EFA_OK;
+        EFA_HIP(hipMemcpyAsync(Wy, Yw + (size_t)w0 * M, (size_t)Pw * M * sizeof(double), hipMemcpyDeviceToDevice, s));
+        EFA_HIP(hipMemcpyAsync(Wm, ymw + w0, (size_t)Pw * sizeof(double), hipMemcpyDeviceToDevice, s));
+        if (extra) {
+          EFA_HIP(hipMemcpyAsync(Wy + (size_t)Pw * M, Yw + (size_t)P * M, (size_t)extra * M * sizeof(double), hipMemcpyDeviceToDevice, s));
+          EFA_HIP(hipMemcpyAsync(Wm + Pw, ymw + P, (size_t)extra * sizeof(double), hipMemcpyDeviceToDevice, s));
+          EFA_HIP(launch_set_identity(M, Wy + (size_t)(Pw + extra) * M, Wm + Pw + extra, s));  // the window's own transform
+        }
+        return EFA_OK;
+      };
+      EFA_TRY(stage_in());
+      EFA_HIP(hipMemsetAsync(c->status.p, 0, 3 * sizeof(int), s));
+      PipeArgs pa{};
+      pa.Yp = Wy;
+      pa.ym = Wm;
+      pa.R = Rw;
+      pa.P = Pw;
+      pa.M = M;
+      pa.ob_value = c->ob_val.as<double>() + w0;
+      pa.ob_error = c->ob_err.as<double>() + w0;
+      pa.ob_assim = c->ob_asm.as<uint8_t>() + w0;
+      pa.ob_errsq = c->ob_errsq.as<double>() + 2 * w0;
+      pa.loc_mode = loc_mode;
+      pa.tw = nullptr;
+      if (loc_mode == EFA_LOC_GC) {
+        EFA_TRY(c->tw_mat.reserve((size_t)Pw * Rw * sizeof(double)));
+        EFA_TRY(c->gc_obtrig.reserve((size_t)Pw * 6 * sizeof(double)));
+        EFA_HIP(launch_obs_taper_matrix(Pw, Rw, c->ob_lat.as<double>() + w0, c->ob_lon.as<double>() + w0, c->ob_hw.as<double>() + w0,
+                                        c->gc_obtrig.as<double>(), c->tw_mat.as<double>(), s));
+        pa.tw = c->tw_mat.as<double>();
+      }
+      pa.coef = c->coef.as<double>() + (size_t)w0 * kCoefStride;
+      pa.prior_mean = c->d_prior_mean.as<double>() + w0;
+      pa.prior_var = c->d_prior_var.as<double>() + w0;
+      pa.post_mean = c->d_post_mean.as<double>() + w0;
+      pa.post_var = c->d_post_var.as<double>() + w0;
+      pa.assimilated = c->d_assimilated.as<uint8_t>() + w0;
+      pa.status = c->status.as<int>();
+      pa.spin_limit = c->spin_limit;
+      pa.spin_ticks = (c->spin_ms >= 0 ? c->spin_ms : 100 + Pw / 100) * 100000L;  // s_memrealtime runs at 100 MHz
+      pa.cu_count = c->cu_count;
+      pa.debug = (int)c->pipe_debug;
+      pa.dbg = nullptr;
+      if (c->pipe_debug & 4) {
+        EFA_TRY(c->dbg.reserve((size_t)P * 8 * sizeof(unsigned long long)));
+        if (w == 0) EFA_HIP(hipMemsetAsync(c->dbg.p, 0, (size_t)P * 8 * sizeof(unsigned long long), s));
+        pa.dbg = c->dbg.as<unsigned long long>() + (size_t)w0 * 8;
+      }
+      // attempt 0: Gram-space leader (option "gram"); attempt 1: vector-chain pipeline.  A failed
+      // attempt (bounded spin expired, or the Gram downdate's cancellation guard) may have let
+      // finished workgroups write their rows back, so the launch's rows are restored before the next.
+      // An attempt is skipped when its grid cannot be co-resident (occupancy query in the launcher), and after an
+      // attempt whose bounded spins EXPIRED (status 1: some workgroups never became resident, e.g. another
+      // kernel holds CUs) the other persistent kernel is not tried either: it has the same residency need.
+      // All windows of a call must leave records of ONE layout (Phase B reads them with one stride): once a window
+      // has run as the band leader, later windows do not fall back to the vector chain (they go to the per-batch kernels).
+      int first_kind = (c->use_gram >= 2 && pipeline_band_supported(M, Rw, loc_mode)) ? 4
+                       : (c->use_gram >= 1 && pipeline_gram_supported(M, Rw, loc_mode)) ? 3 : 1;
+      if (any_pipeline && !traj_kind_band && first_kind == 4) first_kind = (c->use_gram >= 1 && pipeline_gram_supported(M, Rw, loc_mode)) ? 3 : 1;
+      for (int attempt = (first_kind == 1) ? 1 : 0; attempt < 2 && !done; ++attempt) {
+        const int kind = (attempt == 0) ? first_kind : 1;
+        if (any_pipeline && traj_kind_band != (kind == 4)) break;
+        const long TSk = (kind == 4) ? TS_band : TS_std;
+        pa.traj = c->traj.as<unsigned long long>() + (size_t)w0 * TSk;
+        const hipError_t le = kind == 4 ? launch_pipeline_band(pa, s) : kind == 3 ? launch_pipeline_gram(pa, s) : launch_pipeline(pa, s);
+        if (le == hipErrorCooperativeLaunchTooLarge) {
+          (void)hipGetLastError();
+          continue;
+        }
+        EFA_HIP(le);
+        int st[3] = {0, 0, 0};
+        EFA_HIP(hipMemcpyAsync(st, c->status.p, sizeof(st), hipMemcpyDeviceToHost, s));
+        EFA_HIP(hipStreamSynchronize(s));
+        if (st[0] == 0 && st[1] == 0) {
+          done = true;
+          any_pipeline = true;
+          traj_kind_band = (kind == 4);
+          c->phase_a_kind = kind;
+        } else {
+          if (direct) {
+            EFA_HIP(hipMemcpyAsync(Yw, Yp_dev, (size_t)P * M * sizeof(double), hipMemcpyDeviceToDevice, s));
+            EFA_HIP(hipMemcpyAsync(ymw, ym_dev, dP, hipMemcpyDeviceToDevice, s));
+            if (carry_T) EFA_HIP(launch_set_identity(M, Yw + (size_t)P * M, ymw + P, s));
+          } else {
+            EFA_TRY(stage_in());
+          }
+          if (st[2] == 0) break;  // not the Gram guard, so a spin expired: straight to the per-batch kernels
+          if (attempt == 0) {
+            EFA_HIP(launch_fill_u64(c->traj.as<unsigned long long>() + (size_t)w0 * TS, (size_t)Pw * TS, kTrajSentinel, s));
+            EFA_HIP(hipMemsetAsync(c->status.p, 0, 3 * sizeof(int), s));
+          }
+        }
+      }
+      if (done && !direct) {
+        // window rows and transform rows back into the block, then every other row of the block takes the window's records
+        EFA_HIP(hipMemcpyAsync(Yw + (size_t)w0 * M, Wy, (size_t)Pw * M * sizeof(double), hipMemcpyDeviceToDevice, s));
+        EFA_HIP(hipMemcpyAsync(ymw + w0, Wm, (size_t)Pw * sizeof(double), hipMemcpyDeviceToDevice, s));
+        if (extra) {
+          EFA_HIP(hipMemcpyAsync(Yw + (size_t)P * M, Wy + (size_t)Pw * M, (size_t)extra * M * sizeof(double), hipMemcpyDeviceToDevice, s));
+          EFA_HIP(hipMemcpyAsync(ymw + P, Wm + Pw, (size_t)extra * sizeof(double), hipMemcpyDeviceToDevice, s));
+        }
+        const long TSk = traj_kind_band ? TS_band : TS_std;
+        const double* yebase = reinterpret_cast<const double*>(c->traj.p);
+        if (extra) {  // unlocalised: rows [0, w0) and [w1, P) through the window's transform, in place
+          for (int part = 0; part < 2; ++part) {
+            const long lo = part ? w1 : 0, hi = part ? P : w0;
+            if (hi <= lo) continue;
+            TransformArgs t{};
+            t.Xin = Yw + (size_t)lo * M;
+            t.xin = ymw + lo;
+            t.Xout = Yw + (size_t)lo * M;
+            t.xout = ymw + lo;
+            t.nrows = hi - lo;
+            t.M = M;
+            t.T = Wy + (size_t)(Pw + extra) * M;
+            t.w = Wm + Pw + extra;
+            t.fused_members = 0;
+            EFA_HIP(launch_transform(t, s));
+          }
+        }
+        for (long b0 = w0; !extra && b0 < w1; b0 += B) {
+          const int nb = (int)((w1 - b0 < B) ? (w1 - b0) : B);
+          long act = 0;
+          for (int k = 0; k < nb; ++k) act += ob_assim[b0 + k] ? 1 : 0;
+          if (act == 0) continue;
+          EFA_TRY(sweep_rows(b0, nb, yebase + (size_t)b0 * TSk, TSk, w0, w1, P));  // rows [0, P) but the window's own
+        }
+      }
+    }
+    if (!done) {
+      if (any_pipeline) {
+        // records of this window must look like the pipeline's (one stride for Phase B): the per-batch kernels write
+        // dense ye rows, which are copied into the records' layout afterwards
+        EFA_TRY(batch_window(w0, w1));
+        const long TSk = traj_kind_band ? TS_band : TS_std;
+        EFA_HIP(hipMemsetAsync(reinterpret_cast<double*>(c->traj.p) + (size_t)w0 * TSk, 0, (size_t)Pw * TSk * sizeof(double), s));
+        EFA_HIP(hipMemcpy2DAsync(reinterpret_cast<double*>(c->traj.p) + (size_t)w0 * TSk, (size_t)TSk * sizeof(double),
+                                 c->Ye_rec.as<double>() + (size_t)w0 * M, (size_t)M * sizeof(double), (size_t)M * sizeof(double),
+                                 (size_t)Pw, hipMemcpyDeviceToDevice, s));
+      } else if (w == 0) {
+        // nothing has run as a pipeline: the whole call goes to the per-batch kernels
+        EFA_TRY(batch_window(0, P));
+        any_batch = true;
+        break;
+      } else {
+        return fail(EFA_ERR_UNSUPPORTED, "internal: mixed Phase-A layouts");
+      }
+    }
+  }
+  if (any_batch || !any_pipeline) {
+    c->ye_ptr = c->Ye_rec.as<double>();
+    c->ye_stride = M;
+    c->phase_a_kind = 2;
+  } else {
+    c->ye_ptr = reinterpret_cast<const double*>(c->traj.p);
+    c->ye_stride = traj_kind_band ? TS_band : TS_std;
   }
   EFA_HIP(hipMemcpyAsync(Yp_dev, Yw, (size_t)P * M * sizeof(double), hipMemcpyDeviceToDevice, s));
   EFA_HIP(hipMemcpyAsync(ym_dev, ymw, dP, hipMemcpyDeviceToDevice, s));
@@ -760,7 +877,7 @@ int efa_ctx_destroy(efa_ctx* c) {
   if (c->ev_fs) (void)hipEventDestroy(c->ev_fs);
   DevBuf* bufs[] = {&c->ob_pack, &c->out_pack, &c->Ye_rec, &c->coef, &c->ob_val, &c->ob_err, &c->ob_asm, &c->ob_lat, &c->ob_lon, &c->ob_hw, &c->ob_errsq,
                     &c->d_prior_mean, &c->d_prior_var, &c->d_post_mean, &c->d_post_var, &c->d_assimilated,
-                    &c->Yw, &c->ymw, &c->traj, &c->tw_mat, &c->status, &c->dbg, &c->W, &c->gc_cnt, &c->gc_ub, &c->gc_order, &c->gc_obtrig, &c->gc_off, &c->gc_idx, &c->gc_wts, &c->gc_pairs, &c->glat, &c->glon, &c->xm_ws, &c->fs_idx, &c->fs_wts, &c->f_glat, &c->f_glon, &c->f_sl, &c->f_cl, &c->f_valids, &c->f_var, &c->f_time, &c->f_lat, &c->f_lon, &c->f_near, &c->f_idx, &c->f_wts, &c->f_status, &c->h_xm, &c->h_Xp, &c->h_ym, &c->h_Yp,
+                    &c->Yw, &c->ymw, &c->win_Y, &c->win_m, &c->traj, &c->tw_mat, &c->status, &c->dbg, &c->W, &c->gc_cnt, &c->gc_ub, &c->gc_order, &c->gc_obtrig, &c->gc_off, &c->gc_idx, &c->gc_wts, &c->gc_pairs, &c->glat, &c->glon, &c->xm_ws, &c->fs_idx, &c->fs_wts, &c->f_glat, &c->f_glon, &c->f_sl, &c->f_cl, &c->f_valids, &c->f_var, &c->f_time, &c->f_lat, &c->f_lon, &c->f_near, &c->f_idx, &c->f_wts, &c->f_status, &c->h_xm, &c->h_Xp, &c->h_ym, &c->h_Yp,
                     &c->gcc_lat, &c->gcc_lon, &c->gcc_oblat, &c->gcc_oblon, &c->gcc_obhw, &c->gcc_coef, &c->gcc_trig, &c->gcc_cnt, &c->gcc_pairs};
   for (DevBuf* b : bufs) b->release();
   for (int i = 0; i < 4; ++i)

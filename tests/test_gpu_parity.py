@@ -589,6 +589,81 @@ def test_persistent_phase_a_at_its_residency_limit():
         ctx.set_option("path", 0)
 
 
+@pytest.mark.parametrize("loc", [False, True])
+def test_phase_a_in_windows_beyond_one_persistent_launch(loc):
+    """More observations than one persistent launch can hold (256 workgroups x 64 rows): Phase A runs window by
+    window -- each window one persistent launch, every other row of the obs block taking the window's records through the
+    sweep kernel -- and must give what the per-batch kernels give for all P obs (and, on a prefix, what the oracle gives).
+    40 000 obs x 100 members without localisation (three windows, the carried transform rows in each), 20 000 x 40 with
+    Gaspari-Cohn (two windows, obs-obs taper)."""
+    import time
+    ctx = _ctx()
+    M, P = (100, 40000) if not loc else (40, 20000)
+    rng = np.random.default_rng(91)
+    HX = 3.0 * rng.standard_normal((P, M)) + rng.standard_normal((P, 1))
+    val = HX.mean(axis=1) + rng.standard_normal(P)
+    err = rng.uniform(0.5, 2.0, P)
+    asm = rng.random(P) < 0.95
+    kw = {}
+    if loc:
+        kw = dict(loc_mode=1, ob_lat=rng.uniform(-60, 60, P), ob_lon=rng.uniform(0, 360, P), ob_halfwidth=rng.uniform(300, 900, P))
+    res = {}
+    try:
+        for name, pipe in (("batch", 0), ("windows", 1)):
+            ctx.set_option("pipeline", pipe)
+            ctx.set_option("path", 1 if loc else 2)
+            Yp = ctx.to_device(HX)
+            ym = ctx.empty((P,))
+            ctx.form_perts(P, M, Yp, ym, Yp)
+            ctx.synchronize()
+            t0 = time.perf_counter()
+            d = ctx.obs_phase(M, P, ym, Yp, val, err, asm, **kw)
+            dt = time.perf_counter() - t0
+            kind = ctx.get_option("phase_a_kind")
+            assert kind == (2 if pipe == 0 else 4), (name, kind)
+            res[name] = (Yp.download(), ym.download(), d)
+            print("%s: %.2f us per ob (host wall time of the call, P = %d, M = %d, loc = %s)" % (name, 1e6 * dt / P, P, M, loc))
+            if name == "windows" and not loc:     # the transform the windows leave behind serves Phase B
+                X = rng.standard_normal((500, M))
+                xm = ctx.to_device(X.mean(axis=1))
+                Xp = ctx.to_device(X - X.mean(axis=1, keepdims=True))
+                ctx.state_phase(500, M, xm, Xp, xm, Xp)
+                res["T"] = (xm.download(), Xp.download(), X)
+        a, b = res["windows"], res["batch"]
+        assert_parity(a[0], b[0], "final obs perturbations, windows vs per-batch")
+        assert_parity(a[1], b[1], "final obs means")
+        for key in ("prior_mean", "prior_var", "post_mean", "post_var"):
+            assert_parity(a[2][key], b[2][key], key)
+        assert np.array_equal(a[2]["assimilated"], b[2]["assimilated"])
+        # oracle on a prefix (obs k is only influenced by earlier obs): 400 obs, with 500 state rows riding along
+        n = 400
+        ym0, Yp0 = orc.compute_ob_priors(HX[:n])
+        okw = {}
+        if loc:
+            okw = dict(loc="GC", ob_lat=kw["ob_lat"][:n], ob_lon=kw["ob_lon"][:n], ob_halfwidth=kw["ob_halfwidth"][:n],
+                       grid_lat=np.zeros((1, 0)), grid_lon=np.zeros((1, 0)), state_shape=(1, 1, 1, 0))
+        _, _, od = orc.ensrf_update(ym0, Yp0, 0, val[:n], err[:n], asm[:n], **okw)
+        for key in ("prior_mean", "prior_var", "post_mean", "post_var"):
+            assert_parity(a[2][key][:n], od[key], "oracle prefix " + key)
+        if not loc:   # the carried transform after three windows == the sweep of all obs over the same rows (per-batch trajectory)
+            xm_t, Xp_t, X = res["T"]
+            ctx.set_option("pipeline", 0)
+            ctx.set_option("path", 1)
+            Yp = ctx.to_device(HX)
+            ym = ctx.empty((P,))
+            ctx.form_perts(P, M, Yp, ym, Yp)
+            ctx.obs_phase(M, P, ym, Yp, val, err, asm)
+            xm = ctx.to_device(X.mean(axis=1))
+            Xp = ctx.to_device(X - X.mean(axis=1, keepdims=True))
+            ctx.state_phase(500, M, xm, Xp, xm, Xp)
+            assert_parity(Xp_t, Xp.download(), "state rows: transform carried through three windows vs sweep")
+            assert_parity(xm_t, xm.download(), "state means")
+    finally:
+        ctx.set_option("pipeline", 1)
+        ctx.set_option("gram", GRAM_DEFAULT)
+        ctx.set_option("path", 0)
+
+
 def test_helper_kernels_vs_oracle():
     ctx = _ctx()
     rng = np.random.default_rng(8)
