@@ -75,6 +75,7 @@ def parse_args():
     ap.add_argument("--obs-batch", type=int, default=None)
     ap.add_argument("--gram", type=int, default=None, help="Phase-A leader in Gram space (library default if omitted)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-host-api", action="store_true", help="skip the PCIe-inclusive EnSRF.update() timing (N = 1)")
     ap.add_argument("--cpu-rows", type=int, default=0, help="rows of the CPU-baseline sample (0: sized to --cpu-seconds)")
     ap.add_argument("--cpu-obs", type=int, default=8, help="timed observations of the CPU baseline (BASELINE.md 3)")
     ap.add_argument("--cpu-warm", type=int, default=2, help="warm-up observations of the CPU baseline")
@@ -136,6 +137,33 @@ def cpu_baseline(fetch_sample, rows_full, M, nwarm, ntimed, budget_s, fixed_rows
                 sample="NumPy oracle (faithful_cost: the reference's passes and temporaries) on the first %d rows x %d "
                        "members of the same synthetic state, %d warm-up + %d timed obs (%.3f s/ob on the sample), scaled "
                        "linearly to %d rows" % (rows_s, M, nwarm, ntimed, per_ob, rows_full))
+
+
+def host_api_timing(device):
+    """configs[1] (512 x 512 grid x 50 members x 1 000 obs, loc=None) through the Python API from HOST memory:
+    `EnSRF(state, obs).update()` with plain `Observation`s -- upload of the state, forward operator on the device,
+    Phase A, Phase B, download into a new state object.  The PCIe-inclusive time; never the `value`."""
+    from efa_xray_amd import EnsembleState, Observation, EnSRF
+    rng = np.random.default_rng(77)
+    ny = nx = 512
+    M, P = 50, 1000
+    lat, lon = np.meshgrid(np.linspace(20, 60, ny), np.linspace(200, 280, nx), indexing="ij")
+    arr = rng.standard_normal((1, 1, ny, nx, 1)) + 3.0 * rng.standard_normal((1, 1, ny, nx, M))
+    state = EnsembleState.from_array(arr, lat, lon)
+    obs = [Observation(value=float(rng.standard_normal()), obtype="var0", time=0, error=1.0, lat=float(rng.uniform(21, 59)),
+                       lon=float(rng.uniform(201, 279)), assimilate_this=True) for _ in range(P)]
+    times, dev = [], []
+    for _ in range(4):
+        flt = EnSRF(state, obs, verbose=False, loc=None, device=device)
+        t0 = time.perf_counter()
+        post, _ = flt.update()
+        times.append(time.perf_counter() - t0)
+        dev.append(flt.last_timing["obs_ms"] + flt.last_timing["state_ms"])
+    assert np.isfinite(post.to_vect()[:64]).all()
+    nbytes = arr.nbytes
+    return {"workload": "configs[1] through EnSRF.update() from host memory (state %.0f MB up, %.0f MB down, pageable)" % (nbytes / 1e6, nbytes / 1e6),
+            "pcie_inclusive_ms": 1e3 * min(times[1:]), "device_phase_ms": float(np.median(dev[1:])),
+            "host_passes_over_state": "1 upload (slab by slab from the variables) + 1 download (into the new state's arrays)"}
 
 
 def load_traffic(workload, path_name):
@@ -435,6 +463,10 @@ def main():
             out["cpu_baseline"] = cpu_baseline(fetch_sample, rows, M, args.cpu_warm, min(args.cpu_obs, max(P - args.cpu_warm, 1)),
                                                args.cpu_seconds, args.cpu_rows,
                                                dict(unit_rows=unit_rows, max_units=max_units))
+        if world == 1 and args.workload == "headline" and not args.no_host_api:
+            X = post = r = None
+            torch.cuda.empty_cache()
+            out["host_api"] = host_api_timing(local_rank)
         print(json.dumps(out))
     if world > 1:
         dist.destroy_process_group()

@@ -205,6 +205,23 @@ class DeviceArray(object):
         _check(self.ctx.lib, self.ctx.lib.efa_memcpy_d2h(self.ctx.handle, out.ctypes.data, self.ptr, self.nbytes))
         return out
 
+    def upload_rows(self, r0, host):
+        """Rows [r0, r0 + len(host)) from a C-contiguous float64 host array, straight from the caller's memory."""
+        host = np.ascontiguousarray(host, dtype=np.float64)
+        width = int(np.prod(self.shape[1:], dtype=np.int64)) if len(self.shape) > 1 else 1
+        assert host.size % width == 0 and r0 * width * 8 + host.nbytes <= self.nbytes
+        dst = ctypes.c_void_p(self.ptr.value + r0 * width * 8)
+        _check(self.ctx.lib, self.ctx.lib.efa_memcpy_h2d(self.ctx.handle, dst, host.ctypes.data, host.nbytes))
+
+    def download_rows_into(self, r0, out):
+        """Rows [r0, r0 + out.size / width) into `out` (C-contiguous float64), without an intermediate array."""
+        assert out.dtype == np.float64 and out.flags["C_CONTIGUOUS"]
+        width = int(np.prod(self.shape[1:], dtype=np.int64)) if len(self.shape) > 1 else 1
+        assert out.size % width == 0 and r0 * width * 8 + out.nbytes <= self.nbytes
+        src = ctypes.c_void_p(self.ptr.value + r0 * width * 8)
+        _check(self.ctx.lib, self.ctx.lib.efa_memcpy_d2h(self.ctx.handle, out.ctypes.data, src, out.nbytes))
+        return out
+
     def download_rows(self, r0, r1):
         """Rows [r0, r1) of a 2-D (or 1-D) array, without copying the rest."""
         width = int(np.prod(self.shape[1:], dtype=np.int64)) if len(self.shape) > 1 else 1

@@ -7,6 +7,7 @@ Same contract as the reference's `Assimilation`
 `format_posterior_state`.  The array work of the two `format_*` helpers runs on
 the GPU through libefa_hip (efa_form_perts_dev / efa_posterior_dev).
 """
+from collections import OrderedDict
 from copy import deepcopy
 
 import numpy as np
@@ -146,6 +147,29 @@ class Assimilation(object):
                     scale_var(k, float(v))
         self.is_inflated = True
 
+    # -- the state between host and device: one pass each way, variable by variable ----------------
+    def _upload_prior(self, ctx):
+        """The prior as an (nstate, nmems) device array in `to_vect()` order (ensemble.py:110-114), copied slab by slab
+        from each variable's own (nt, ny, nx, nmem) array: no stacked host copy of the state is made."""
+        prior = self.prior
+        N, M = prior.nstate(), prior.nmems()
+        X = ctx.empty((max(N, 1), M))
+        per = prior.ntimes() * prior.ny() * prior.nx()
+        for iv, name in enumerate(prior.vars()):
+            X.upload_rows(iv * per, prior.variables[name])
+        return X
+
+    def _download_posterior(self, X):
+        """A NEW state object like the prior (assimilation.py:165 deep-copies it) whose variables are the rows of the device
+        array `X`: coordinates are copied, member arrays are downloaded straight into their own fresh arrays."""
+        prior = self.prior
+        per = prior.ntimes() * prior.ny() * prior.nx()
+        shape = prior.shape()[1:]
+        variables = OrderedDict()
+        for iv, name in enumerate(prior.vars()):
+            variables[name] = X.download_rows_into(iv * per, np.empty(shape, dtype=np.float64))
+        return type(prior)(variables, deepcopy(prior.coords))
+
     def _default_forward_operator(self):
         """True when every ob uses `Observation.estimate` as shipped (the reference's point interpolation,
         observation.py:40-50): then all P estimates are computed on the device.  An ob whose class or
@@ -195,23 +219,24 @@ class Assimilation(object):
         ctx.forward_interp(ncol, 0, ncol, nvar * nt, M, X_dev, HX)
         return HX
 
-    def compute_ob_estimates(self):
+    def compute_ob_estimates(self, X_dev=None):
         """(P, M) ensemble estimates HX[k] = ob_k.estimate(prior): the forward operator loop of
         assimilation.py:45-46.  With the reference's own point-interpolation operator the whole loop runs on
-        the device (`device_ob_estimates`); user-defined `estimate` methods are called one by one."""
+        the device (`device_ob_estimates`, on the resident copy `X_dev` of the prior if the caller has one);
+        user-defined `estimate` methods are called one by one."""
         nobs = len(self.obs)
         if self._default_forward_operator():
             ctx = self._context()
-            X = ctx.to_device(np.ascontiguousarray(self.prior.to_vect(), dtype=np.float64))
+            X = X_dev if X_dev is not None else self._upload_prior(ctx)
             return self.device_ob_estimates(ctx, X).download()
         HX = np.zeros((nobs, self.prior.nmems()))
         for k, ob in enumerate(self.obs):
             HX[k, :] = ob.estimate(self.prior)
         return HX
 
-    def compute_ob_priors(self):
+    def compute_ob_priors(self, X_dev=None):
         """Obs-space prior means and perturbations (assimilation.py:36-49)."""
-        HX = self.compute_ob_estimates()
+        HX = self.compute_ob_estimates(X_dev)
         P, M = HX.shape
         if P == 0:
             return np.zeros(0), np.zeros((0, M))
@@ -229,11 +254,10 @@ class Assimilation(object):
             if self.verbose:
                 print("Inflating Prior State")
             self.inflate_state()
-        obmeans, obperts = self.compute_ob_priors()
-        X = np.ascontiguousarray(self.prior.to_vect(), dtype=np.float64)
-        N, M = X.shape
         ctx = self._context()
-        d = ctx.to_device(X)
+        d = self._upload_prior(ctx)                    # ONE upload serves the forward operator and the perturbations
+        obmeans, obperts = self.compute_ob_priors(d)
+        N, M = self.prior.nstate(), self.prior.nmems()
         m = ctx.empty((N,))
         ctx.form_perts(N, M, d, m, d)
         xbm = np.hstack((m.download(), obmeans))
@@ -248,6 +272,4 @@ class Assimilation(object):
         d = ctx.to_device(np.ascontiguousarray(Xap[:N]))
         m = ctx.to_device(np.ascontiguousarray(xam[:N]))
         ctx.posterior(N, M, m, d, d)
-        post_state = deepcopy(self.prior)
-        post_state.from_vect(d.download())
-        return post_state, self.obs
+        return self._download_posterior(d), self.obs

@@ -12,8 +12,6 @@ The per-observation loop (ensrf.py:50-149) does not exist in Python here:
 and calls libefa_hip (`efa_obs_phase_dev` + `efa_state_cycle_dev`).  If the
 library or a gfx950 GPU is missing the call raises -- there is no NumPy path.
 """
-from copy import deepcopy
-
 import numpy as np
 
 from efa_xray_amd import _lib
@@ -97,7 +95,7 @@ class EnSRF(Assimilation):
         ctx.set_option("timing", 1)
         if self.verbose:
             print("Converting state to vector")
-        X = ctx.to_device(np.ascontiguousarray(prior.to_vect(), dtype=np.float64))
+        X = self._upload_prior(ctx)                            # slab by slab from the variables: no stacked host copy
         # forward operator, once per ob from the prior (assimilation.py:45-48): on the device for the
         # reference's point interpolation, through ob.estimate() for user-defined operators
         if self.verbose:
@@ -121,7 +119,6 @@ class EnSRF(Assimilation):
         diag = ctx.obs_phase(M, P, ym, Yp, value, error, assim, loc_mode, lat, lon, hw)
         ctx.state_cycle(N, M, X, X, grid_lat, grid_lon, n_lead)
         self.last_timing = ctx.last_timing()
-        post = X.download()
 
         # diagnostics onto the observations, as ensrf.py:66,70,75,146-149
         for k, ob in enumerate(self.obs):
@@ -136,8 +133,9 @@ class EnSRF(Assimilation):
 
         if self.verbose:
             print("Formatting posterior")
-        post_state = deepcopy(self.prior)                       # assimilation.py:165
-        post_state.from_vect(post)
+        # a NEW state object (assimilation.py:165 deep-copies the prior): coordinates copied, member arrays downloaded
+        # straight into their own fresh arrays -- the prior's members are not copied only to be overwritten
+        post_state = self._download_posterior(X)
         return post_state, self.obs
 
     # ------------------------------------------------------------------

@@ -280,8 +280,8 @@ __global__ __launch_bounds__(256, (NC * (RPL + 1) <= 30) ? EFA_GC_MINWAVES : (NC
   // blockIdx.x = (position in the longest-first order) * lead_split + (group of slabs): a shard with few, long
   // column blocks (the polar ranks of a cost-balanced split) still fills the device and has no tail of whole blocks
   const long b = a.order[blockIdx.x / a.lead_split];
-  const long lead_lo = (long)(blockIdx.x % a.lead_split) * a.lead_chunk;
-  const long lead_hi = (lead_lo + a.lead_chunk < a.n_lead) ? lead_lo + a.lead_chunk : a.n_lead;
+  const int lead_lo = (int)(blockIdx.x % a.lead_split) * (int)a.lead_chunk;
+  const int lead_hi = (lead_lo + (int)a.lead_chunk < (int)a.n_lead) ? lead_lo + (int)a.lead_chunk : (int)a.n_lead;
   // quad r of wave w: column cq of the block, slab slot sq of the group of slabs
   const int cq = EFA_GC_COLSPLIT ? 4 * wave + (r & 3) : r;
   const int sq = EFA_GC_COLSPLIT ? (r >> 2) : wave;
@@ -294,7 +294,7 @@ __global__ __launch_bounds__(256, (NC * (RPL + 1) <= 30) ? EFA_GC_MINWAVES : (NC
   // A quad holds RPL rows of the SAME column (slabs lead, lead + 4, ...): they share the taper and
   // every ye row read from LDS (the quad layout delivers each ye row once per quad), and a staged
   // chunk serves 4 RPL slabs instead of 4.
-  for (long lead0 = lead_lo; lead0 < lead_hi; lead0 += 4 * RPL) {
+  for (int lead0 = lead_lo; lead0 < lead_hi; lead0 += 4 * RPL) {
     double x[RPL][2 * NC];
     double xm[RPL];
     bool live[RPL];
@@ -302,10 +302,10 @@ __global__ __launch_bounds__(256, (NC * (RPL + 1) <= 30) ? EFA_GC_MINWAVES : (NC
     bool any_live = false;
 #pragma unroll
     for (int q = 0; q < RPL; ++q) {
-      const long lead = lead0 + sq + 4 * q;
+      const int lead = lead0 + sq + 4 * q;
       live[q] = col_ok && lead < lead_hi;
       any_live = any_live || live[q];
-      row[q] = lead * a.ncol + col;
+      row[q] = (long)lead * a.ncol + col;
       xm[q] = 0.0;
       if (live[q]) {
         load_row<L, NC, VEC>(a.Xin + (size_t)row[q] * M, M, j, x[q]);
