@@ -118,7 +118,7 @@ struct efa_ctx {
   long obs_batch = 64;
   long path = EFA_PATH_AUTO;
   long timing = 0;
-  long use_gram = 2;       // persistent kernel's leader: 2 band leader (unlocalised) else Gram leader, 1 Gram leader, 0 vector chain
+  long use_gram = 2;       // persistent kernel's leader: 2 band leader (with and without localisation), 1 Gram leader step by step, 0 vector chain
   long use_pipeline = 1;   // persistent Phase-A kernel when it applies (else per-batch kernels)
   long spin_limit = 4000000;
   long spin_ms = -1;       // wall-time bound of the persistent Phase-A launch; -1: 100 ms + P/100 ms
@@ -680,7 +680,7 @@ int state_sweeps(efa_ctx* c, long rows, const double* xm_in, const double* Xp_in
   const int M = c->M;
   const long P = c->P;
   hipStream_t s = c->stream;
-  if (c->loc_mode == EFA_LOC_GC && c->gc_onepass && M <= 128 && c->n_active > 0)
+  if (c->loc_mode == EFA_LOC_GC && c->gc_onepass && c->n_active > 0)  // every ensemble size the library accepts (2..256)
     return state_gc_onepass(c, rows, xm_in, Xp_in, xm_out, Xp_out, ncol, rows / ncol, 0);
   const long B = effective_batch(c, M);
   bool first = true;
@@ -1161,7 +1161,7 @@ int efa_state_cycle_dev(efa_ctx* c, long rows, int M, const double* X_dev, doubl
     EFA_HIP(efa::launch_transform(t, s));
     c->state_launches = 1;
     c->path_taken = EFA_PATH_TRANSFORM;
-  } else if (c->loc_mode == EFA_LOC_GC && c->gc_onepass && M <= 128 && c->n_active > 0) {
+  } else if (c->loc_mode == EFA_LOC_GC && c->gc_onepass && c->n_active > 0) {
     // localised: prior members -> posterior members in one read + one write of the state
     EFA_TRY(state_gc_onepass(c, rows, nullptr, X_dev, nullptr, post_dev, ncol, n_lead, 1));
   } else {

@@ -1,4 +1,5 @@
-// Persistent Phase-A pipeline, BAND leader ("k_pipe_band"), unlocalised cycles only.
+// Persistent Phase-A pipeline, BAND leader ("k_pipe_band"): unlocalised cycles and, since the end of round 2,
+// Gaspari-Cohn cycles (template parameter GC: the obs-obs taper of the block in LDS, two-term downdates).
 //
 // Same launch structure, follower code and inter-workgroup protocol as efa_pipeline_gram.hip (one
 // workgroup per 64 obs rows, rows resident in registers, sentinel-validated agent-scope trajectory
@@ -13,14 +14,19 @@
 // the waves exchange data once per band:
 //
 //   pivot wave   keeps the band's 4 rows of G (lane = column) in registers and runs the 4 steps of
-//                the Gram-space recurrence alone: chain scalars by v_readlane, the rows of the band
-//                that follow are downdated in registers.  Per step it publishes {G_kj, kb_j}; per band
-//                the obs' scalars and the inverse of the band's unit lower triangular factor
+//                the Gram-space recurrence alone: the chain carries ONE gain constant per ob,
+//                c = beta / ((M-1) kdenom) (gain_c), the band's later rows are downdated in registers, the
+//                ob constants arrive by wave-uniform loads one band ahead.  Per step it publishes {G_kj, kb_j};
+//                per band the inverse of the band's unit lower triangular factor
 //                (ye_{r0+s} = y_{r0+s} - sum_{t<s} kb^{(t)}_{r0+s} ye_{r0+t}  <=>  YE = L^-1 Y).
+//                (Round 3: no mean chain -- a block whose pivot rows are not centred goes to the vector-chain kernel --
+//                and no per-ob latches: the forwarder wave recomputes 1/kdenom and beta from the recorded G_kk.)
 //   2 G waves    hold G as matrix-core accumulator tiles (two tile columns each) and apply a
 //                band's downdates as matrix-core updates per tile (v_mfma_f64_16x16x4_f64, from the step
-//                records alone: A = -G_ki, B = kb_j and A = -kb_i, B = t_j); the next band's rows go first
-//                and are handed to the pivot wave through LDS half a band early.
+//                records alone: A = -G_ki, B = gamma G_kj without localisation; A = -G_ki, B = kb_j and
+//                A = -kb_i, B = t_j with it).  They run ONE BAND BEHIND the pivot wave: after band b the rows of
+//                band b+2 go back to it first (round 3: the pivot <-> G-wave round trip through LDS flags, ~2.4 k
+//                cycles, is then off the chain; the pivot applies band b+1 to those rows itself).
 //   4 vector waves  hold 16 consecutive block rows each as accumulator tiles.  The band's four rows are one
 //                register of ONE wave, already in B-operand layout: that wave forms YE = L^-1 Y for every
 //                column tile from its registers, publishes it in the ring and applies the band to its own

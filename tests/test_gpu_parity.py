@@ -16,7 +16,7 @@ pytestmark = pytest.mark.gpu
 RTOL = 1e-10
 
 
-GRAM_DEFAULT = 2  # library default of the "gram" option (2: band leader when unlocalised, else the Gram leader)
+GRAM_DEFAULT = 2  # library default of the "gram" option (2: band leader, with and without localisation)
 
 
 def _ctx():
@@ -811,7 +811,8 @@ def test_gc_goldens_per_batch_table_path(name):
 
 
 @pytest.mark.parametrize("N,M,P,ncol", [(3 * 48 * 64, 40, 300, 48 * 64), (5 * 700, 80, 150, 700), (2 * 1000, 100, 64, 1000),
-                                        (7 * 333, 2, 40, 333), (1 * 257, 128, 33, 257), (6 * 64, 6, 20, 64)])
+                                        (7 * 333, 2, 40, 333), (1 * 257, 128, 33, 257), (6 * 64, 6, 20, 64),
+                                        (2 * 300, 130, 40, 300), (3 * 200, 200, 30, 200), (1 * 100, 256, 20, 100)])
 def test_one_pass_gc_sweep_vs_oracle_ragged_shapes(N, M, P, ncol):
     """The one-pass localised sweep against the oracle, in perturbation form and as prior members -> posterior
     members, on shapes whose column count is not a multiple of the 16-column block and whose slab count is not a
