@@ -220,6 +220,11 @@ __global__ __launch_bounds__(kGT) void k_pipe_band(const PipeArgs a) {
 #else
 #define EFA_EXP(bit) false
 #endif
+#ifdef EFA_PIPE_PIVSTAMP
+#define EFA_HO(row, slot) do { if (a.dbg != nullptr && lane == 0 && own0 + (row) < P) a.dbg[(size_t)(own0 + (row)) * 8 + (slot)] = __builtin_amdgcn_s_memrealtime(); } while (0)
+#else
+#define EFA_HO(row, slot) do { } while (0)
+#endif
 #ifdef EFA_PIPE_PIVSTAMP  /* make pivstamp: wait / work accounting of the pivot and G waves only (they have registers to spare) */
 #define EFA_PS_NOW() __builtin_amdgcn_s_memtime()
 #define EFA_PS(stmt) stmt
@@ -370,6 +375,7 @@ __global__ __launch_bounds__(kGT) void k_pipe_band(const PipeArgs a) {
       }
     };
     follow(0, (own0 < P) ? own0 : P);
+    if (leads) EFA_HO(8, 0);   // T2: the last foreign record is in this workgroup's ring
     EFA_BLOCKSTAMP(lane == 0 && leads, 3);
     EFA_WAIT_OUT(lane == 0 && leads, 4, 6, __builtin_amdgcn_s_memrealtime());  // 100 MHz, comparable across workgroups
 #ifdef EFA_PIPE_BLOCKTIME
@@ -409,17 +415,30 @@ __global__ __launch_bounds__(kGT) void k_pipe_band(const PipeArgs a) {
           l_be = mine ? be : l_be;
           l_var = mine ? Gkk * invM : l_var;                                   // np.var, ddof = 0 (:69, :70): the rows are centred
         }
-        for (int s = 0; s < s1; ++s) {
+        // Every LDS operand of the band first (ONE round trip for its up to four records: the forwarder used to pay three
+        // per record and was as slow as the pivot wave), then the serial mean chain of its steps, then the stores.
+        double2 gk4[kBand];
+        double yv[kBand][EPL], tw4[kBand];
+#pragma unroll
+        for (int s = 0; s < kBand; ++s) {
+          const int st = kBand * b + ((s < s1) ? s : 0);
+          const double* slot = ring + (size_t)((own0 + st) % kRingG) * TSR;
+          gk4[s] = s_gk[st * kRowsWG + lane];                                  // G_kj, kb_j of this lane's row
+          tw4[s] = GC ? tw_s[st * kRowsWG + lane] : 1.0;
+#pragma unroll
+          for (int e = 0; e < EPL; ++e) yv[s][e] = slot[(lane + 64 * e < PAD) ? lane + 64 * e : 0];
+        }
+#pragma unroll
+        for (int s = 0; s < kBand; ++s) {
+          if (s >= s1) break;  // wave-uniform
           const int st = kBand * b + s;
           const long f = own0 + st;
-          const double* slot = ring + (size_t)(f % kRingG) * TSR;
-          const double2 gk = s_gk[st * kRowsWG + lane];                        // G_kj, kb_j of this lane's row
           const double rden = rl(l_rd, st), beta_k = rl(l_be, st);
           const bool act = ((asm_mask >> st) & 1) != 0;
           const double xmk = rl(xmv, st);
           const double innov = rl(val_l, st) - xmk;                            // :85
-          double kc = gk.x * rM1;                                              // :95
-          if (GC) kc = tw_s[st * kRowsWG + lane] * kc;                         // :115
+          double kc = gk4[s].x * rM1;                                          // :95
+          if (GC) kc = tw4[s] * kc;                                            // :115
           const double km = act ? kc * rden : 0.0;                             // :119
           xmv = xmv + km * innov;                                              // :130
           l_xm = (lane == st) ? xmk : l_xm;                                    // this lane's ob: its prior mean (:66)
@@ -430,12 +449,10 @@ __global__ __launch_bounds__(kGT) void k_pipe_band(const PipeArgs a) {
           for (int e = 0; e < EPL; ++e) {
             const int idx = lane + 64 * e;
             if (64 * (e + 1) <= PAD) {
-              g_traj_store(rec + idx, slot[idx]);
+              g_traj_store(rec + idx, yv[s][e]);
             } else if (idx < TS) {
-              // one LDS read per lane (the tail of ye), then register selects for the four scalars: values of this
-              // wave, so no hand-off between lanes is involved
-              const int sj = idx - PAD;
-              double v = slot[sj < 0 ? idx : 0];
+              const int sj = idx - PAD;  // >= 0: one of the four scalars (values of this wave: no hand-off between lanes)
+              double v = yv[s][e];
               v = (sj == 0) ? rden : v;
               v = (sj == 1) ? beta_k : v;
               v = (sj == 2) ? innov : v;
@@ -443,8 +460,8 @@ __global__ __launch_bounds__(kGT) void k_pipe_band(const PipeArgs a) {
               g_traj_store(rec + idx, v);
             }
           }
-          if (lane == 0) g_ctl_set(&ctl[cFwd], (int)f);
         }
+        if (lane == 0) g_ctl_set(&ctl[cFwd], (int)(own0 + kBand * b + s1 - 1));  // ring slots up to here are free again
       }
       // The obs' diagnostics and sweep coefficients, once per block and one ob per lane, from what is in LDS anyway:
       // km of the ob's own row is kc rden with kc = G_kk/(M-1), and that row is scaled by (1 - kb_k)  (:144-149).
@@ -468,6 +485,7 @@ __global__ __launch_bounds__(kGT) void k_pipe_band(const PipeArgs a) {
           a.post_var[f] = (fsc * fsc) * var;
         }
       }
+      EFA_HO(8, 1);   // T1: this block's last record has been forwarded
       pm[kRowsWG + lane] = xmv;  // obs-space means of all 64 rows after the block, back to the vector waves
       EFA_BLOCKSTAMP(lane == 0, 2);
       EFA_WAIT_OUT(lane == 0, 4, 5, __builtin_amdgcn_s_memrealtime());
@@ -496,8 +514,10 @@ __global__ __launch_bounds__(kGT) void k_pipe_band(const PipeArgs a) {
       }
     }
     __syncthreads();  // B1
+    if (wave == kVW) EFA_HO(8, 2);   // T3: every vector wave has parked its rows
     form_gram();
     __syncthreads();  // B2
+    if (wave == kVW) EFA_HO(8, 3);   // T4: G is complete
     if (wave == kVW) {
       // ---------------- pivot wave: lane j <-> column j of G ----------------
       __builtin_amdgcn_s_setprio(3);  // the serial chain: ahead of the vector wave that shares its SIMD
@@ -546,6 +566,7 @@ __global__ __launch_bounds__(kGT) void k_pipe_band(const PipeArgs a) {
       for (int o = 0; o < kBand - kEarly; ++o) gprev[o] = gamprev[o] = kbprev[o] = tprev[o] = 0.0;
       EFA_BLOCKSTAMP(lane == 0, 0);
       EFA_WAIT_OUT(lane == 0, 5, 5, __builtin_amdgcn_s_memrealtime());
+      EFA_HO(8, 4);   // T5: the pivot starts band 0
       EFA_PS(u64 ps_wait = 0; const u64 ps_t0 = EFA_PS_NOW();)
       for (int b = 0; b < nbands && ok; ++b) {
         const int r0 = kBand * b;
@@ -647,6 +668,7 @@ __global__ __launch_bounds__(kGT) void k_pipe_band(const PipeArgs a) {
           g_ctl_set(&ctl[cLinv], b + 1);
         }
       }
+      EFA_HO(8, 5);   // T0: the pivot has finished the block's last step
       EFA_PS(if (a.dbg != nullptr && lane == 0) {
         a.dbg[(size_t)own0 * 8 + 0] = EFA_PS_NOW() - ps_t0;
         a.dbg[(size_t)own0 * 8 + 1] = ps_wait;

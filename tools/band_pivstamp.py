@@ -33,6 +33,18 @@ for h in (0, 1):
     r = [med(lambda b, i=i: t[64 * b + h, 2 + i]) for i in range(5)]
     print("G wave %d per block: wait first half %.0f | phase 1 %.0f (its operand loads %.0f) | wait band end %.0f | phase 2 %.0f  (sum %.0f)"
           % (h, r[0], r[1], r[4], r[2], r[3], sum(r[:4])))
+# the hand-over chain between consecutive blocks, absolute s_memrealtime stamps (10 ns ticks) in row own0 + 8
+rt = lambda b, c: int(t[64 * b + 8, c])
+ch = []
+for b in range(2, nb - 2):
+    T0, T1 = rt(b, 5), rt(b, 1)                                   # leader b: pivot done, last record forwarded
+    T2, T3, T4, T5 = rt(b + 1, 0), rt(b + 1, 2), rt(b + 1, 3), rt(b + 1, 4)   # leader b+1
+    if min(T0, T1, T2, T3, T4, T5) > 0:
+        ch.append((T1 - T0, T2 - T1, T3 - T2, T4 - T3, T5 - T4, T5 - T0, rt(b + 1, 5) - T5))
+ch = np.array(ch) * 10.0 * 2.39   # -> shader cycles at 2.39 GHz
+if len(ch):
+    print("hand-over chain (median cycles): pivot done -> last record forwarded %.0f | -> in next leader's ring %.0f | -> its rows parked (B1) %.0f | -> Gram done (B2) %.0f | -> its pivot starts %.0f ;  total %.0f ; its pivot loop %.0f"
+          % tuple(np.median(ch, axis=0)))
 # per band (rows own0+64+b of the NEXT block's stamp rows hold band b of block own0): absolute s_memtime stamps
 ev = []
 for blk in range(2, nb - 2):
