@@ -66,25 +66,7 @@ static_assert(PLg == 4 && kRowsWG == 64, "layout assumptions of the band kernel"
 
 // control words (ints in LDS)
 static_assert(true, "");
-enum { cReady = 0, cBail = 1, cSReady = 2, cFwd = 3, cProg = 4 /* ..7 */, cBandH = 8 /* ..9 */, cLinv = 10, cPark = 11, cYe = 12, cHalf = 13,
-       cSnap = 14, cGsnap = 15 };
-// EARLY GRAM (round 3).  A workgroup's Gram matrix used to be formed between the block-start barriers, after its vector waves
-// had applied the last foreign record and parked their rows: 7.6 k cycles of matrix-core work on the serial chain
-// (profiles/r03_phase_a_pivot_loop.txt).  Now the vector waves park a SNAPSHOT of their rows kEGRecs records before the
-// block; the three waves that only wait for the block (pivot, two G waves) form G from it and then follow the remaining
-// foreign records in Gram space, band by band, from what the vector waves compute anyway and publish per record and row:
-// d_j = y_j . ye_k and the gain kb_j:   G_ij -= d_i kb_j + kb_i (d_j - kb_j |ye_k|^2).
-// At the block-start barrier G is complete; only its tiles go to LDS.  The followers publish for EVERY record (two LDS
-// stores per row: a separate publishing loop, or a branch, costs the register file more than it saves -- the kernel sits at
-// 235 of 256 registers); the slots, in G's place in LDS, are a ring of kEGRecs records.  |ye_k|^2 travels as the record's
-// "active" scalar (0 for an ob that is not assimilated, which downdates nothing).
-#ifndef EFA_EARLY_GRAM
-#define EFA_EARLY_GRAM 1
-#endif
-constexpr int kEGBands = 6;                // bands of foreign records between the snapshot and the block
-constexpr int kEGRecs = kEGBands * kBand;  // 24
-constexpr int kEGStride = kRowsWG + 1;     // double2 per record: {d_j, kb_j} for the 64 rows, then {|ye_k|^2, -}
-static_assert((size_t)kEGRecs * kEGStride * 2 <= (size_t)kRowsWG * kRowsWG, "the published dots live in G's place until the block starts");
+enum { cReady = 0, cBail = 1, cSReady = 2, cFwd = 3, cProg = 4 /* ..7 */, cBandH = 8 /* ..9 */, cLinv = 10, cPark = 11, cYe = 12, cHalf = 13 };
 #ifndef EFA_EARLY
 #define EFA_EARLY 0
 #endif
@@ -209,10 +191,6 @@ __global__ __launch_bounds__(kGT) void k_pipe_band(const PipeArgs a) {
   const int nb = (int)(own1 - own0);  // obs this workgroup leads (0: it only follows)
   const bool leads = nb > 0;
   const int nbands = (nb + kBand - 1) / kBand;
-  // early Gram: every leading workgroup that has at least kEGRecs foreign records before its block (all but the first)
-  const bool early = EFA_EARLY_GRAM && leads && own0 >= kEGRecs;
-  const long snap_k = own0 - kEGRecs;
-  double* sdk = G_s;  // [kEGRecs][2 kEGStride]: published {d_j, kb_j}, |ye_k|^2 -- in G's place until the block starts
   const double rM1 = 1.0 / (double)(M - 1);
   const double invM = 1.0 / (double)M;
 
@@ -408,7 +386,7 @@ __global__ __launch_bounds__(kGT) void k_pipe_band(const PipeArgs a) {
 #endif
     if (leads && !failed) {
       __syncthreads();  // B1: the vector waves have parked their rows in the tile
-      if (!early) form_gram();
+      form_gram();
       __syncthreads();  // B2: G is complete
       barriers_left = 1;
       // This wave also carries the obs-space MEANS of the block's 64 rows (lane j = row j) and everything that
@@ -421,7 +399,6 @@ __global__ __launch_bounds__(kGT) void k_pipe_band(const PipeArgs a) {
       const u64 asm_mask = __ballot(f_ob ? (a.ob_assim[own0 + lane] != 0) : false);
       double l_xm = 0.0;
       double l_var = 0.0, l_rd = 0.0, l_be = 0.0;  // this lane's ob: prior variance, 1/kdenom, beta -- from G_kk at its step
-      double l_g = 0.0;                             // ... and G_kk = |ye_k|^2 itself (the record's "active" scalar: early Gram)
       for (int b = 0; b < nbands && !failed; ++b) {
         // the band's ye rows are in the ring once every vector wave has added its tiles (4 per band)
         if (!wait_gt(&ctl[cYe], 4 * (b + 1) - 1, true)) {
@@ -437,7 +414,6 @@ __global__ __launch_bounds__(kGT) void k_pipe_band(const PipeArgs a) {
           l_rd = mine ? rd : l_rd;
           l_be = mine ? be : l_be;
           l_var = mine ? Gkk * invM : l_var;                                   // np.var, ddof = 0 (:69, :70): the rows are centred
-          l_g = mine ? Gkk : l_g;
         }
         // Every LDS operand of the band first (ONE round trip for its up to four records: the forwarder used to pay three
         // per record and was as slow as the pivot wave), then the serial mean chain of its steps, then the stores.
@@ -468,7 +444,7 @@ __global__ __launch_bounds__(kGT) void k_pipe_band(const PipeArgs a) {
           l_xm = (lane == st) ? xmk : l_xm;                                    // this lane's ob: its prior mean (:66)
           // record = ye, then the four scalars the followers read: rden, beta, innov, active
           u64* rec = a.traj + (size_t)f * TS;
-          const double actv = act ? rl(l_g, st) : 0.0;  // non-zero <=> assimilated; the value is |ye_k|^2 (zero only if ye_k = 0: no update either way)
+          const double actv = act ? 1.0 : 0.0;
 #pragma unroll
           for (int e = 0; e < EPL; ++e) {
             const int idx = lane + 64 * e;
@@ -537,92 +513,9 @@ __global__ __launch_bounds__(kGT) void k_pipe_band(const PipeArgs a) {
         tw_s[i] = (kg < P && rg < R) ? a.tw[(size_t)kg * R + rg] : 1.0;
       }
     }
-    // ---- early Gram: G from the snapshot, then the remaining foreign records in Gram space ----
-    v4f64 eg[6];
-    bool eg_ok = true;
-    auto eg_run = [&](auto Atag) {
-      constexpr int A3 = decltype(Atag)::value;         // this wave's tiles: t = A3, A3 + 3, ... (t = 4 I + J)
-      constexpr int NT = (16 - A3 + 2) / 3;
-      const int lr = lane >> 4, lc = lane & 15;
-      if (!wait_gt(&ctl[cSnap], kVW - 1, true)) {        // all four vector waves have parked the snapshot
-        eg_ok = false;
-        return;
-      }
-#pragma unroll
-      for (int i = 0; i < NT; ++i) {
-        constexpr int dummy = 0;
-        (void)dummy;
-        const int t = A3 + 3 * i, I = t >> 2, J = t & 3;
-        v4f64 acc = {0.0, 0.0, 0.0, 0.0};
-        const double* pa = Yt + (size_t)(16 * I + lc) * SP + lr;
-        const double* pb = Yt + (size_t)(16 * J + lc) * SP + lr;
-        for (int s = 0; s < PAD / 4; ++s) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(pa[4 * s], pb[4 * s], acc, 0, 0, 0);
-        eg[i] = acc;
-      }
-      asm volatile("" ::: "memory");
-      if (lane == 0) __hip_atomic_fetch_add(&ctl[cGsnap], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);  // the tile is free
-      for (int eb = 0; eb < kEGBands && eg_ok; ++eb) {
-        const int last = (int)(snap_k + kBand * eb + kBand - 1);  // every vector wave must have applied this record
-        for (;;) {
-          int mn = g_ctl_lane(&ctl[cProg + (lane & 3)]);
-          mn = min(mn, __builtin_amdgcn_mov_dpp(mn, 0xB1, 0xF, 0xF, true));
-          mn = min(mn, __builtin_amdgcn_mov_dpp(mn, 0x4E, 0xF, 0xF, true));
-          if (__builtin_amdgcn_readfirstlane(mn) >= last) break;
-          if ((++polls & 15) == 0) {
-            if (g_ctl(&ctl[cBail]) != 0) { eg_ok = false; break; }
-            budget -= 16;
-            if (budget <= 0 || EFA_TIMED_OUT()) { give_up(); eg_ok = false; break; }
-          }
-          __builtin_amdgcn_s_sleep(1);
-        }
-        if (!eg_ok) break;
-        // operands of the band: lane (lc, lr) <-> row 16 q + lc of the block, record kBand eb + lr.  The same values
-        // serve as A[i = lc][k = lr] and B[k = lr][j = lc].
-        const double2* rec = reinterpret_cast<const double2*>(sdk) + (size_t)((snap_k + kBand * eb + lr) % kEGRecs) * kEGStride;
-        const double ee = rec[kRowsWG].x;                 // |ye_k|^2
-        double a1[4], a2[4], b1[4], b2[4];
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-          double2 dk = rec[16 * q + lc];                  // d, kb
-          if (ee == 0.0) dk = make_double2(0.0, 0.0);     // not assimilated: the followers skipped it, its slots are stale
-          a1[q] = -dk.x;
-          a2[q] = -dk.y;
-          b1[q] = dk.y;
-          b2[q] = __builtin_fma(-dk.y, ee, dk.x);
-        }
-#pragma unroll
-        for (int i = 0; i < NT; ++i) {
-          const int t = A3 + 3 * i, I = t >> 2, J = t & 3;
-          eg[i] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1[I], b1[J], eg[i], 0, 0, 0);
-          eg[i] = __builtin_amdgcn_mfma_f64_16x16x4f64(a2[I], b2[J], eg[i], 0, 0, 0);
-        }
-      }
-    };
-    auto eg_store = [&](auto Atag) {  // the tiles into G_s (D layout: row = 4 v + lane/16, col = lane%16)
-      constexpr int A3 = decltype(Atag)::value;
-      constexpr int NT = (16 - A3 + 2) / 3;
-      const int lr = lane >> 4, lc = lane & 15;
-#pragma unroll
-      for (int i = 0; i < NT; ++i) {
-        const int t = A3 + 3 * i, I = t >> 2, J = t & 3;
-#pragma unroll
-        for (int v = 0; v < 4; ++v) G_s[(16 * I + 4 * v + lr) * kRowsWG + 16 * J + lc] = eg[i][v];
-      }
-    };
-    if (early) {
-      if (wave == kVW) eg_run(std::integral_constant<int, 0>());
-      else if (wave == kVW + 1) eg_run(std::integral_constant<int, 1>());
-      else eg_run(std::integral_constant<int, 2>());
-    }
     __syncthreads();  // B1
     if (wave == kVW) EFA_HO(8, 2);   // T3: every vector wave has parked its rows
-    if (early) {
-      if (wave == kVW) eg_store(std::integral_constant<int, 0>());
-      else if (wave == kVW + 1) eg_store(std::integral_constant<int, 1>());
-      else eg_store(std::integral_constant<int, 2>());
-    } else {
-      form_gram();
-    }
+    form_gram();
     __syncthreads();  // B2
     if (wave == kVW) EFA_HO(8, 3);   // T4: G is complete
     if (wave == kVW) {
@@ -980,32 +873,14 @@ __global__ __launch_bounds__(kGT) void k_pipe_band(const PipeArgs a) {
   }
   int barriers_left = leads ? 3 : 0;
   bool bailed = false;
-  bool snapped = false;
   long k = 0;
-  // as a follower this wave goes ahead of the wave that shares its SIMD: the three waiting waves' matrix-core work for the
-  // early Gram must fill the gaps of this wave's arithmetic, not the other way round
-  __builtin_amdgcn_s_setprio(2);
   while (k < P && !bailed) {
-    if (early && !snapped && k == snap_k) {
-      // early Gram: a snapshot of the rows for the three waiting waves; this wave goes on following
-#pragma unroll
-      for (int c = 0; c < NC; ++c)
-        *reinterpret_cast<double2*>(Yt + (size_t)i_loc * SP + 2 * PLg * c + 2 * j) = make_double2(x[2 * c], x[2 * c + 1]);
-      asm volatile("" ::: "memory");
-      if (lane == 0) __hip_atomic_fetch_add(&ctl[cSnap], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-      snapped = true;
-    }
     if (leads && k == own0) {
       // ---------------- this workgroup's block ----------------
-      __builtin_amdgcn_s_setprio(0);
 #ifdef EFA_PIPE_BLOCKTIME
       if (a.dbg != nullptr && lane == 0) a.dbg[(size_t)(own0 + wave) * 8 + 4] = __builtin_amdgcn_s_memtime();  // per vector wave
       EFA_WAIT_OUT(wave == 0 && lane == 0, 4, 7, __builtin_amdgcn_s_memrealtime());
 #endif
-      if (early && !wait_gt(&ctl[cGsnap], 2, false)) {  // the three waiting waves have read the snapshot out of the tile
-        bailed = true;
-        break;
-      }
 #pragma unroll
       for (int c = 0; c < NC; ++c)
         *reinterpret_cast<double2*>(Yt + (size_t)i_loc * SP + 2 * PLg * c + 2 * j) = make_double2(x[2 * c], x[2 * c + 1]);
@@ -1016,7 +891,7 @@ __global__ __launch_bounds__(kGT) void k_pipe_band(const PipeArgs a) {
       }
       __syncthreads();  // B1: tile and parked means complete
       EFA_BLOCKSTAMP(wave == 0 && lane == 0, 5);
-      if (!early) form_gram();
+      form_gram();
       // For the block the rows change layout: wave w takes block rows 16 w .. 16 w + 15 as NJ accumulator tiles of
       // v_mfma_f64_16x16x4_f64: register v of tile J in lane l is member 16 J + (l & 15) of block row
       // 16 w + 4 v + (l >> 4).  A band's four rows are then register v = (band & 3) of ONE wave, already in the
@@ -1118,7 +993,6 @@ __global__ __launch_bounds__(kGT) void k_pipe_band(const PipeArgs a) {
       }
       xm = pm[kRowsWG + i_loc];  // the pivot wave carried the obs-space means through the block (:130)
       k = own1;
-      __builtin_amdgcn_s_setprio(2);
       continue;
     }
     // ---------------- follower steps: consume the records that are in the ring ----------------
@@ -1131,8 +1005,7 @@ __global__ __launch_bounds__(kGT) void k_pipe_band(const PipeArgs a) {
       break;
     }
     long avail = g_ctl(&ctl[cReady]);
-    long lim = (leads && k < own0) ? own0 : P;
-    if (early && !snapped && snap_k < lim) lim = snap_k;  // a batch ends exactly where the snapshot is taken
+    const long lim = (leads && k < own0) ? own0 : P;
     if (avail > lim) avail = lim;
     if (avail > k + kRingG / 2) avail = k + kRingG / 2;  // progress is reported at least every half ring (slot recycling)
     double ya[2 * NC], yb2[2 * NC];
@@ -1145,11 +1018,8 @@ __global__ __launch_bounds__(kGT) void k_pipe_band(const PipeArgs a) {
       s01 = *reinterpret_cast<const double2*>(slot + PAD);      // rden, beta
       s23 = *reinterpret_cast<const double2*>(slot + PAD + 2);  // innov, active
     };
-    auto apply = [&](const double (&y)[2 * NC], const double2 s01, const double2 s23, const double w, const long kk) {
+    auto apply = [&](const double (&y)[2 * NC], const double2 s01, const double2 s23, const double w) {
       if (EFA_EXP(4096)) return;  // timing experiment: followers do no arithmetic
-      // early Gram: every record's {y_j . ye_k, kb_j} and |ye_k|^2 (s23.y, 0 if not assimilated) go to a ring of LDS slots
-      double* rd = sdk + (size_t)(kk % kEGRecs) * (2 * kEGStride);
-      if (wave == 0 && lane == 0) rd[2 * kRowsWG] = s23.y;
       if (__builtin_amdgcn_readfirstlane((int)(s23.y != 0.0)) != 0) {
         const double dot = group_dot<PLg, NC>(x, y);
         double kc = dot * rM1;                              // :95
@@ -1157,10 +1027,6 @@ __global__ __launch_bounds__(kGT) void k_pipe_band(const PipeArgs a) {
         const double km = kc * s01.x;                       // :119
         xm = xm + km * s23.x;                               // :130
         const double kb = s01.y * km;                       // :136
-        if (j == 0) {
-          rd[2 * i_loc] = dot;
-          rd[2 * i_loc + 1] = kb;
-        }
 #pragma unroll
         for (int c = 0; c < 2 * NC; ++c) x[c] = __builtin_fma(-kb, y[c], x[c]);  // :141
       }
@@ -1168,11 +1034,11 @@ __global__ __launch_bounds__(kGT) void k_pipe_band(const PipeArgs a) {
     fetch(k, ya, a01, a23, wa);
     while (k < avail) {
       if (k + 1 < avail) fetch(k + 1, yb2, b01, b23, wb);
-      apply(ya, a01, a23, wa, k);
+      apply(ya, a01, a23, wa);
       ++k;
       if (k >= avail) break;
       if (k + 1 < avail) fetch(k + 1, ya, a01, a23, wa);
-      apply(yb2, b01, b23, wb, k);
+      apply(yb2, b01, b23, wb);
       ++k;
     }
     if (lane == 0) g_ctl_set(&ctl[cProg + wave], (int)(k - 1));
