@@ -79,8 +79,14 @@ enum { cReady = 0, cBail = 1, cSReady = 2, cFwd = 3, cProg = 4 /* ..7 */, cBandH
 // kEarly == 0 (default): the G waves run one whole band behind.  After band b they hand over the rows of band b + 2,
 //   current through band b; the pivot wave, which needs them a full band later, applies band b + 1 to them itself (16 row
 //   updates per band instead of 12).  The round trip has a band's time to complete: the pivot never waits.
-constexpr int kEarly = EFA_EARLY;
-static_assert(kEarly >= 0 && kEarly < kBand, "early hand-over");
+// With Gaspari-Cohn localisation a row update of the pivot wave is two-term (two v_readlane pairs): the 16 updates per band of
+// the one-band-behind scheme then cost what the wait did, and the hand-over after ONE step measures best (configs[3]'s
+// Phase A 6.98 ms against 7.14).
+#ifndef EFA_EARLY_GC
+#define EFA_EARLY_GC 1
+#endif
+constexpr int kEarlyNone = EFA_EARLY, kEarlyGC = EFA_EARLY_GC;
+static_assert(kEarlyNone >= 0 && kEarlyNone < kBand && kEarlyGC >= 0 && kEarlyGC < kBand, "early hand-over");
 constexpr int kScStride = 4;  // doubles per ob: rden, beta (latched by the pivot wave), innov, active (added by the forwarder): the record's scalars
 
 __device__ __forceinline__ u64 g_traj_load(const u64* p) {
@@ -168,6 +174,7 @@ template <int NC, bool GC>
 __global__ __launch_bounds__(kGT) void k_pipe_band(const PipeArgs a) {
   using Sh = BandShape<NC, GC>;
   constexpr int PAD = Sh::PAD, TS = Sh::TS, TSR = Sh::TSR, SP = Sh::SP, UREG = Sh::UREG;
+  constexpr int kEarly = GC ? kEarlyGC : kEarlyNone;
   constexpr int EPL = (TS + 63) / 64;
   constexpr int NJ = (PAD + 15) / 16;  // accumulator tiles per vector wave in the block's matrix-core layout
   extern __shared__ __align__(16) double lds[];
