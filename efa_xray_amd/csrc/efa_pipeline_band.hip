@@ -458,10 +458,14 @@ __global__ __launch_bounds__(kGT) void k_pipe_band(const PipeArgs a) {
             if (64 * (e + 1) <= PAD) {
               g_traj_store(rec + idx, yv[s][e]);
             } else if (idx < TS) {
-              const int sj = idx - PAD;  // >= 0: one of the four scalars (values of this wave: no hand-off between lanes)
+              // >= 0: one of the scalars (values of this wave: no hand-off between lanes).  The followers read two:
+              // c = beta / ((M-1) kdenom), 0 for an ob that is not assimilated, and m = innov / ((M-1) kdenom):
+              // kb_j = w c (y_j . ye), xm_j += w m (y_j . ye)   (:95, :115, :119, :130, :136 folded once per ob)
+              const int sj = idx - PAD;
+              const double cf = act ? (beta_k * rden) * rM1 : 0.0, mf = (rden * rM1) * innov;
               double v = yv[s][e];
-              v = (sj == 0) ? rden : v;
-              v = (sj == 1) ? beta_k : v;
+              v = (sj == 0) ? cf : v;
+              v = (sj == 1) ? mf : v;
               v = (sj == 2) ? innov : v;
               v = (sj >= 3) ? actv : v;
               g_traj_store(rec + idx, v);
@@ -1016,36 +1020,33 @@ __global__ __launch_bounds__(kGT) void k_pipe_band(const PipeArgs a) {
     if (avail > lim) avail = lim;
     if (avail > k + kRingG / 2) avail = k + kRingG / 2;  // progress is reported at least every half ring (slot recycling)
     double ya[2 * NC], yb2[2 * NC];
-    double2 a01, a23, b01, b23;
+    double2 a01, b01;
     double wa = 1.0, wb = 1.0;  // GC: taper of the record's ob against this row (obs-obs table, fetched with the record)
-    auto fetch = [&](long kk, double (&y)[2 * NC], double2& s01, double2& s23, double& w) {
+    auto fetch = [&](long kk, double (&y)[2 * NC], double2& s01, double& w) {
       const double* slot = ring + (size_t)(kk % kRingG) * TSR;
       if (GC) w = slot[TS + i_loc];  // put there by the loader wave together with the record
       lds_read_row<PLg, NC>(slot, j, y);
-      s01 = *reinterpret_cast<const double2*>(slot + PAD);      // rden, beta
-      s23 = *reinterpret_cast<const double2*>(slot + PAD + 2);  // innov, active
+      s01 = *reinterpret_cast<const double2*>(slot + PAD);      // c (0: not assimilated), m
     };
-    auto apply = [&](const double (&y)[2 * NC], const double2 s01, const double2 s23, const double w) {
+    auto apply = [&](const double (&y)[2 * NC], const double2 s01, const double w) {
       if (EFA_EXP(4096)) return;  // timing experiment: followers do no arithmetic
-      if (__builtin_amdgcn_readfirstlane((int)(s23.y != 0.0)) != 0) {
-        const double dot = group_dot<PLg, NC>(x, y);
-        double kc = dot * rM1;                              // :95
-        if (GC) kc = w * kc;                                // :115
-        const double km = kc * s01.x;                       // :119
-        xm = xm + km * s23.x;                               // :130
-        const double kb = s01.y * km;                       // :136
+      if (__builtin_amdgcn_readfirstlane((int)(s01.x != 0.0)) != 0) {
+        double dot = group_dot<PLg, NC>(x, y);              // :95
+        if (GC) dot = w * dot;                              // :115
+        xm = __builtin_fma(s01.y, dot, xm);                 // :119, :130
+        const double kb = s01.x * dot;                      // :119, :136
 #pragma unroll
         for (int c = 0; c < 2 * NC; ++c) x[c] = __builtin_fma(-kb, y[c], x[c]);  // :141
       }
     };
-    fetch(k, ya, a01, a23, wa);
+    fetch(k, ya, a01, wa);
     while (k < avail) {
-      if (k + 1 < avail) fetch(k + 1, yb2, b01, b23, wb);
-      apply(ya, a01, a23, wa);
+      if (k + 1 < avail) fetch(k + 1, yb2, b01, wb);
+      apply(ya, a01, wa);
       ++k;
       if (k >= avail) break;
-      if (k + 1 < avail) fetch(k + 1, ya, a01, a23, wa);
-      apply(yb2, b01, b23, wb);
+      if (k + 1 < avail) fetch(k + 1, ya, a01, wa);
+      apply(yb2, b01, wb);
       ++k;
     }
     if (lane == 0) g_ctl_set(&ctl[cProg + wave], (int)(k - 1));
