@@ -664,6 +664,66 @@ def test_phase_a_in_windows_beyond_one_persistent_launch(loc):
         ctx.set_option("path", 0)
 
 
+def test_a_window_that_gives_up_is_redone_by_the_per_batch_kernels():
+    """Two windows (17 000 obs x 100 members).  The second holds 40 near-exact copies of one observation with a tiny
+    error variance: the band leader's cancellation guard trips there (as in
+    `test_gram_leader_cancellation_guard_falls_back`).  The first window has already left band-layout records, so the
+    vector-chain kernel (another record layout) is not an option: the window is redone by the per-batch kernels for its
+    own obs only, its ye rows are copied into the records' layout, and the whole call -- final obs block, diagnostics, the
+    carried transform, the sweep over the recorded trajectory -- must equal the per-batch kernels' result for all P obs."""
+    ctx = _ctx()
+    M, P = 100, 17000
+    rng = np.random.default_rng(123)
+    HX = 3.0 * rng.standard_normal((P, M)) + rng.standard_normal((P, 1))
+    k0 = 16400                                       # inside the second window (it starts at 16 184)
+    HX[k0 + 1:k0 + 40] = HX[k0] + 1e-4 * rng.standard_normal((39, M))
+    val = HX.mean(axis=1) + rng.standard_normal(P)
+    val[k0:k0 + 40] = HX[k0].mean() + 0.1
+    err = np.ones(P)
+    err[k0:k0 + 40] = 1e-8
+    asm = np.ones(P, dtype=bool)
+    X = rng.standard_normal((600, M))
+    res = {}
+    try:
+        for name, pipe in (("batch", 0), ("windows", 1)):
+            for path in (2, 1):
+                ctx.set_option("pipeline", pipe)
+                ctx.set_option("path", path)
+                Yp = ctx.to_device(HX)
+                ym = ctx.empty((P,))
+                ctx.form_perts(P, M, Yp, ym, Yp)
+                d = ctx.obs_phase(M, P, ym, Yp, val, err, asm)
+                kind = ctx.get_option("phase_a_kind")
+                xm = ctx.to_device(X.mean(axis=1))
+                Xp = ctx.to_device(X - X.mean(axis=1, keepdims=True))
+                ctx.state_phase(600, M, xm, Xp, xm, Xp)
+                assert ctx.last_timing()["path"] == path
+                res[name, path] = (Yp.download(), ym.download(), d, xm.download(), Xp.download(), kind)
+        assert res["batch", 2][5] == 2 and res["windows", 2][5] == 4      # the first window did run as the band leader
+        ref = res["batch", 1]
+        for key in (("windows", 2), ("windows", 1), ("batch", 2)):
+            got = res[key]
+            assert_parity(got[0], ref[0], "%s: final obs perturbations" % (key,))
+            assert_parity(got[1], ref[1], "%s: final obs means" % (key,))
+            for dk in ("prior_mean", "prior_var", "post_mean", "post_var"):
+                assert_parity(got[2][dk], ref[2][dk], "%s: %s" % (key, dk))
+            assert_parity(got[3], ref[3], "%s: state means" % (key,))
+            assert_parity(got[4], ref[4], "%s: state perturbations" % (key,))
+        # the guard really tripped in the second window: run its obs alone (one window) and see the fallback kind
+        ctx.set_option("pipeline", 1)
+        ctx.set_option("path", 1)
+        sub = slice(16184, P)
+        Yp = ctx.to_device(HX[sub])
+        ym = ctx.empty((P - 16184,))
+        ctx.form_perts(P - 16184, M, Yp, ym, Yp)
+        ctx.obs_phase(M, P - 16184, ym, Yp, val[sub], err[sub], asm[sub])
+        assert ctx.get_option("phase_a_kind") == 1
+    finally:
+        ctx.set_option("pipeline", 1)
+        ctx.set_option("gram", GRAM_DEFAULT)
+        ctx.set_option("path", 0)
+
+
 def test_helper_kernels_vs_oracle():
     ctx = _ctx()
     rng = np.random.default_rng(8)
