@@ -66,7 +66,7 @@ static_assert(PLg == 4 && kRowsWG == 64, "layout assumptions of the band kernel"
 
 // control words (ints in LDS)
 static_assert(true, "");
-enum { cReady = 0, cBail = 1, cSReady = 2, cFwd = 3, cProg = 4 /* ..7 */, cBandH = 8 /* ..9 */, cLinv = 10, cPark = 11, cYe = 12, cHalf = 13 };
+enum { cReady = 0, cBail = 1, cSReady = 2, cFwd = 3, cProg = 4 /* ..7 */, cBandH = 8 /* ..9 */, cLinv = 10, cPark = 11, cYe = 12, cHalf = 13, cDef = 14 };
 #ifndef EFA_EARLY
 #define EFA_EARLY 0
 #endif
@@ -157,6 +157,9 @@ __device__ __forceinline__ double rl(double v, int lane) {  // value held by `la
 }
 
 
+#ifndef EFA_DEFER_GRAM
+#define EFA_DEFER_GRAM 1
+#endif
 template <int NC, bool GC = false>
 struct BandShape {
   static constexpr int PAD = 2 * PLg * NC;
@@ -166,7 +169,12 @@ struct BandShape {
   static constexpr int UREG = (kRowsWG * SP > kRowsWG * (2 * kRowsWG + kScStride + 1)) ? kRowsWG * SP : kRowsWG * (2 * kRowsWG + kScStride + 1);
   static constexpr int kLinv = kNBands * kBand * kBand;  // L^-1 of every band, [band][t][s]
   static constexpr int kTw = GC ? kRowsWG * kRowsWG : 0;  // the block's 64 x 64 corner of the obs-obs taper table (Gaspari-Cohn cycles)
-  static size_t lds_doubles() { return (size_t)kRingG * TSR + kRowsWG * kRowsWG + UREG + 2 * kRowsWG + kLinv + kTw; }
+  // DEFERRED GRAM (unlocalised cycles): only tile row 0 of G is formed between the block-start barriers; the pivot wave starts
+  // on it while tile rows 1..3 are formed on the other three SIMDs.  The parked tile those products read shares its LDS with
+  // the step records, so the records of the first kSgE steps live in an area of their own.
+  static constexpr bool kDefer = !GC && NC <= 13 && (EFA_DEFER_GRAM != 0);  // (14 chunks and more: the extra registers would spill)
+  static constexpr int kSgE = kDefer ? 16 : 0;               // steps whose records live outside the union
+  static size_t lds_doubles() { return (size_t)kRingG * TSR + kRowsWG * kRowsWG + UREG + 3 * kRowsWG + kLinv + kTw + (size_t)kSgE * kRowsWG * 2; }
   static size_t lds_bytes() { return lds_doubles() * sizeof(double) + 32 * sizeof(int); }
 };
 
@@ -181,12 +189,16 @@ __global__ __launch_bounds__(kGT) void k_pipe_band(const PipeArgs a) {
   double* ring = lds;                          // [kRingG][TSR]  ye rows (+ scalars, + GC taper column in follower mode)
   double* G_s = ring + kRingG * TSR;            // [64][64]       Gram matrix of the block; later the rows handed to the pivot
   double* U = G_s + kRowsWG * kRowsWG;         // union: Yt[64][SP]  then  {g, kb}[64][64], sc[64][8]
-  double* pm = U + UREG;                       // [2][64]        parked row means / obs-space means
-  double* LinvA = pm + 2 * kRowsWG;            // [16 bands][4][4]  L^-1 of each band: LinvA[b][t][s] = (L^-1)[s][t]
+  double* pm = U + UREG;                       // [3][64]        parked row means / obs-space means / squared row norms
+  double* LinvA = pm + 3 * kRowsWG;            // [16 bands][4][4]  L^-1 of each band: LinvA[b][t][s] = (L^-1)[s][t]
   double* tw_s = LinvA + Sh::kLinv;            // [64][64]       GC: taper of the block's obs against the block's rows
-  int* ctl = reinterpret_cast<int*>(tw_s + Sh::kTw);  // [32]
+  double2* sgk_e = reinterpret_cast<double2*>(tw_s + Sh::kTw);  // [kSgE][64]  step records of the first steps (deferred Gram)
+  int* ctl = reinterpret_cast<int*>(reinterpret_cast<double*>(sgk_e) + (size_t)Sh::kSgE * kRowsWG * 2);  // [32]
   double* Yt = U;
   double2* s_gk = reinterpret_cast<double2*>(U);  // [step][row] = {G_kj, kb_j}
+  constexpr bool DEFER = Sh::kDefer;
+  // record of step st (per-lane or uniform st)
+  auto SG = [&](int st) -> double2* { return (DEFER && st < Sh::kSgE) ? sgk_e + (size_t)st * kRowsWG : s_gk + (size_t)st * kRowsWG; };
 
   const int tid = threadIdx.x;
   // wave roles: 0-3 vector, 4 pivot, 5-6 G waves, 7 loader
@@ -291,6 +303,34 @@ __global__ __launch_bounds__(kGT) void k_pipe_band(const PipeArgs a) {
     return __builtin_amdgcn_readfirstlane(mn);
   };
 
+  // one 16 x 16 tile of G = Y Y^T from the parked tile, stored at its place
+  auto gram_tile = [&](int I, int J) {
+    v4f64 acc = {0.0, 0.0, 0.0, 0.0};
+    const double* pa = Yt + (size_t)(16 * I + (lane & 15)) * SP + (lane >> 4);
+    const double* pb = Yt + (size_t)(16 * J + (lane & 15)) * SP + (lane >> 4);
+    for (int s = 0; s < PAD / 4; ++s) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(pa[4 * s], pb[4 * s], acc, 0, 0, 0);
+#pragma unroll
+    for (int v = 0; v < 4; ++v) G_s[(16 * I + 4 * v + (lane >> 4)) * kRowsWG + 16 * J + (lane & 15)] = acc[v];
+  };
+  // deferred Gram: tile rows 1..3 after the second block-start barrier, on the three SIMDs the pivot wave is not on
+  // (waves 1, 2: four tiles each; waves 3 and 7: two each -- 104 matrix-core steps per SIMD); cDef counts finished tiles
+  auto gram_deferred = [&]() {
+    int n = 0;
+    if (wave == 1 || wave == 2) {
+      for (int J = 0; J < 4; ++J) gram_tile(wave, J);
+      n = 4;
+    } else if (wave == 3) {
+      gram_tile(3, 0);
+      gram_tile(3, 1);
+      n = 2;
+    } else if (wave == 7) {
+      gram_tile(3, 2);
+      gram_tile(3, 3);
+      n = 2;
+    }
+    asm volatile("" ::: "memory");
+    if (n && lane == 0) __hip_atomic_fetch_add(&ctl[cDef], n, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+  };
   // G = Y Y^T for the block's rows, every wave takes two 16 x 16 tiles (between the block-start barriers)
   auto form_gram = [&]() {
     const int I = wave >> 1, J0 = (wave & 1) * 2;
@@ -393,9 +433,11 @@ __global__ __launch_bounds__(kGT) void k_pipe_band(const PipeArgs a) {
 #endif
     if (leads && !failed) {
       __syncthreads();  // B1: the vector waves have parked their rows in the tile
-      form_gram();
-      __syncthreads();  // B2: G is complete
+      if (DEFER) gram_tile(0, 3);
+      else form_gram();
+      __syncthreads();  // B2: G is complete (deferred Gram: its tile row 0)
       barriers_left = 1;
+      if (DEFER) gram_deferred();
       // This wave also carries the obs-space MEANS of the block's 64 rows (lane j = row j) and everything that
       // hangs on them -- innovation, mean update (:85, :130), the obs' diagnostics -- from the pivot wave's records:
       // none of it is on the serial chain, and every instruction the pivot wave does not issue shortens a step.
@@ -414,7 +456,7 @@ __global__ __launch_bounds__(kGT) void k_pipe_band(const PipeArgs a) {
         }
         const int s1 = (nb - kBand * b < kBand) ? nb - kBand * b : kBand;
         {  // the band's obs, one per lane: the scalars the pivot wave used at their steps, recomputed from the same G_kk
-          const double Gkk = s_gk[(lane & 63) * kRowsWG + lane].x;
+          const double Gkk = SG(lane & 63)[lane].x;
           double rd, be;
           gain_scalars(Gkk, invM, ec_l.x, ec_l.y, rd, be);
           const bool mine = (lane >> 2) == b;  // kBand == 4
@@ -430,7 +472,7 @@ __global__ __launch_bounds__(kGT) void k_pipe_band(const PipeArgs a) {
         for (int s = 0; s < kBand; ++s) {
           const int st = kBand * b + ((s < s1) ? s : 0);
           const double* slot = ring + (size_t)((own0 + st) % kRingG) * TSR;
-          gk4[s] = s_gk[st * kRowsWG + lane];                                  // G_kj, kb_j of this lane's row
+          gk4[s] = SG(st)[lane];                                  // G_kj, kb_j of this lane's row
           tw4[s] = GC ? tw_s[st * kRowsWG + lane] : 1.0;
 #pragma unroll
           for (int e = 0; e < EPL; ++e) yv[s][e] = slot[(lane + 64 * e < PAD) ? lane + 64 * e : 0];
@@ -478,7 +520,7 @@ __global__ __launch_bounds__(kGT) void k_pipe_band(const PipeArgs a) {
       // km of the ob's own row is kc rden with kc = G_kk/(M-1), and that row is scaled by (1 - kb_k)  (:144-149).
       if (!failed && f_ob) {
         const long f = own0 + lane;
-        const double2 gk = s_gk[lane * kRowsWG + lane];                        // G_kk, kb_k at the ob's own step
+        const double2 gk = SG(lane)[lane];                                     // G_kk, kb_k at the ob's own step
         const double2 rb = make_double2(l_rd, l_be);                           // rden, beta
         const double var = l_var;
         const bool act = ((asm_mask >> lane) & 1) != 0;
@@ -526,7 +568,8 @@ __global__ __launch_bounds__(kGT) void k_pipe_band(const PipeArgs a) {
     }
     __syncthreads();  // B1
     if (wave == kVW) EFA_HO(8, 2);   // T3: every vector wave has parked its rows
-    form_gram();
+    if (DEFER) gram_tile(0, wave - kVW);
+    else form_gram();
     __syncthreads();  // B2
     if (wave == kVW) EFA_HO(8, 3);   // T4: G is complete
     if (wave == kVW) {
@@ -540,7 +583,7 @@ __global__ __launch_bounds__(kGT) void k_pipe_band(const PipeArgs a) {
       const u64 asm_mask = __ballot(my_asm);
       // cancellation guard: an assimilated pivot whose G_kk fell below 1e-3 of its value at block start; accumulated
       // in the loop, acted upon after the block (a tripped guard abandons the launch: nothing produced meanwhile is used)
-      const double gjj0 = G_s[lane * kRowsWG + lane];
+      const double gjj0 = DEFER ? pm[2 * kRowsWG + lane] : G_s[lane * kRowsWG + lane];  // |y_j|^2 at block start
       double thr = my_asm ? 1e-3 * gjj0 : -1.0;
       u64 bad = 0ull;
       bool ok = true;
@@ -590,6 +633,10 @@ __global__ __launch_bounds__(kGT) void k_pipe_band(const PipeArgs a) {
           const int o = (r0 + kBand + s < nb) ? r0 + kBand + s : 0;
           ec_nx[s][0] = ecp[2 * o];
           ec_nx[s][1] = ecp[2 * o + 1];
+        }
+        if (DEFER && r0 == Sh::kSgE) {  // the step records move into the union from here: the parked tile must be done with
+          ok = wait_gt(&ctl[cDef], 11, false);
+          if (!ok) break;
         }
         if (b > 0) {  // the band's rows, current through the previous band, from the two G waves
           EFA_PS(const u64 ps_a = EFA_PS_NOW();)
@@ -655,7 +702,7 @@ __global__ __launch_bounds__(kGT) void k_pipe_band(const PipeArgs a) {
                 linv[s2] = __builtin_fma(-(cc * gi), linv[s], linv[s2]);  // L[s2][s] = kb_i = c G_k,i
               }
             }
-            s_gk[kk * kRowsWG + lane] = make_double2(g, kb);              // the step's record: {G_kj, kb_j} per row
+            SG(kk)[lane] = make_double2(g, kb);              // the step's record: {G_kj, kb_j} per row
             if (s == kEarly - 1 && lane == 0) g_ctl_set(&ctl[cHalf], 2 * b + 1);  // the G waves may start on the next band's rows
             EFA_PS(if (s == kEarly - 1 && a.dbg != nullptr && lane == 0 && own0 + 64 + b < P) a.dbg[(size_t)(own0 + 64 + b) * 8 + 0] = EFA_PS_NOW();)
             if (s >= kEarly) {
@@ -705,12 +752,19 @@ __global__ __launch_bounds__(kGT) void k_pipe_band(const PipeArgs a) {
     const int h = wave - kVW - 1;  // 0, 1
     const int lr = lane >> 4, lc = lane & 15;
     v4f64 acc[4][2];
+    auto load_acc = [&](int I0, int I1) {
 #pragma unroll
-    for (int I = 0; I < 4; ++I)
+      for (int I = 0; I < 4; ++I)
+        if (I >= I0 && I < I1)
 #pragma unroll
-      for (int jj = 0; jj < 2; ++jj)
+          for (int jj = 0; jj < 2; ++jj)
 #pragma unroll
-        for (int v = 0; v < 4; ++v) acc[I][jj][v] = G_s[(16 * I + 4 * v + lr) * kRowsWG + 16 * (2 * h + jj) + lc];
+            for (int v = 0; v < 4; ++v) acc[I][jj][v] = G_s[(16 * I + 4 * v + lr) * kRowsWG + 16 * (2 * h + jj) + lc];
+    };
+    static_assert(!DEFER || kEarly == 0, "the deferred Gram is written for the one-band-behind G waves");
+    if (DEFER) __builtin_amdgcn_s_setprio(2);  // ahead of the vector wave on this SIMD, which forms deferred Gram tiles back to back
+    load_acc(0, DEFER ? 1 : 4);  // deferred Gram: tile rows 1..3 are not there yet
+    bool rows_ready = !DEFER;
     EFA_PS(u64 ps_w1 = 0; u64 ps_p1 = 0; u64 ps_w2 = 0; u64 ps_p2 = 0; u64 ps_l1 = 0;)
     // From the records {G_kj, kb_j} alone: G_ij -= kb_j G_ki + kb_i (G_kj - kb_j G_kk), two products per K slice of
     // four steps: (A1 = -G_ki, B1 = kb_j) and (A2 = -kb_i, B2 = t_j).  Steps outside [lo, hi) of the band are masked.
@@ -723,7 +777,7 @@ __global__ __launch_bounds__(kGT) void k_pipe_band(const PipeArgs a) {
         const int sb = 4 * q + lr;                            // this lane's K slot: step r0 + sb
         const bool on = sb >= lo && sb < hi;
         const int st = r0 + (on ? sb : 0);
-        const double2 dg = s_gk[st * kRowsWG + st];           // G_kk, kb_k
+        const double2 dg = SG(st)[st];                        // G_kk, kb_k
         const double Gkk = dg.x;
         double gam = 0.0;
         if (!GC) {
@@ -732,7 +786,7 @@ __global__ __launch_bounds__(kGT) void k_pipe_band(const PipeArgs a) {
         }
 #pragma unroll
         for (int jj = 0; jj < 2; ++jj) {
-          const double2 r = s_gk[st * kRowsWG + 16 * (2 * h + jj) + lc];
+          const double2 r = SG(st)[16 * (2 * h + jj) + lc];
           if (GC) {
             b1[q][jj] = on ? r.y : 0.0;
             b2[q][jj] = on ? __builtin_fma(-r.y, Gkk, r.x) : 0.0;
@@ -749,7 +803,7 @@ __global__ __launch_bounds__(kGT) void k_pipe_band(const PipeArgs a) {
       for (int q = 0; q < kBand / 4; ++q) {
         const int sb = 4 * q + lr;
         const bool on = sb >= lo && sb < hi;
-        const double2 r = s_gk[(r0 + (on ? sb : 0)) * kRowsWG + 16 * I + lc];  // A[i = lc][s = lr]
+        const double2 r = SG(r0 + (on ? sb : 0))[16 * I + lc];  // A[i = lc][s = lr]
         const double a1 = on ? -r.x : 0.0, a2 = on ? -r.y : 0.0;
 #pragma unroll
         for (int jj = 0; jj < 2; ++jj) {
@@ -788,6 +842,18 @@ __global__ __launch_bounds__(kGT) void k_pipe_band(const PipeArgs a) {
         const int r0 = kBand * b;
         const int I2 = (r0 + 2 * kBand) >> 4;  // tile row of band b + 2
         if (!wait_gt(&ctl[cSReady], r0 + kBand - 1, false)) break;
+        if (DEFER && !rows_ready && (I2 > 0 || g_ctl(&ctl[cDef]) >= 12)) {
+          // tile rows 1..3 of G have arrived (or are needed now): take them, and give them the bands they owe
+          if (!wait_gt(&ctl[cDef], 11, false)) break;
+          load_acc(1, 4);
+          for (int bb = 0; bb < b; ++bb) {
+            load_b(kBand * bb, 0, kBand);
+            update_row(std::integral_constant<int, 1>(), kBand * bb, 0, kBand);
+            update_row(std::integral_constant<int, 2>(), kBand * bb, 0, kBand);
+            update_row(std::integral_constant<int, 3>(), kBand * bb, 0, kBand);
+          }
+          rows_ready = true;
+        }
         load_b(r0, 0, kBand);
         switch (I2) {
           case 0: update_row(std::integral_constant<int, 0>(), r0, 0, kBand); hand_over(std::integral_constant<int, 0>(), r0 + 2 * kBand); break;
@@ -796,9 +862,11 @@ __global__ __launch_bounds__(kGT) void k_pipe_band(const PipeArgs a) {
           default: update_row(std::integral_constant<int, 3>(), r0, 0, kBand); hand_over(std::integral_constant<int, 3>(), r0 + 2 * kBand); break;
         }
         if (lane == 0) g_ctl_set(&ctl[cBandH + h], b + 2);
-        if (I2 < 1) update_row(std::integral_constant<int, 1>(), r0, 0, kBand);
-        if (I2 < 2) update_row(std::integral_constant<int, 2>(), r0, 0, kBand);
-        if (I2 < 3) update_row(std::integral_constant<int, 3>(), r0, 0, kBand);
+        if (rows_ready) {  // (else: owed, see above)
+          if (I2 < 1) update_row(std::integral_constant<int, 1>(), r0, 0, kBand);
+          if (I2 < 2) update_row(std::integral_constant<int, 2>(), r0, 0, kBand);
+          if (I2 < 3) update_row(std::integral_constant<int, 3>(), r0, 0, kBand);
+        }
       }
       __syncthreads();  // B3
       return;
@@ -896,13 +964,15 @@ __global__ __launch_bounds__(kGT) void k_pipe_band(const PipeArgs a) {
       for (int c = 0; c < NC; ++c)
         *reinterpret_cast<double2*>(Yt + (size_t)i_loc * SP + 2 * PLg * c + 2 * j) = make_double2(x[2 * c], x[2 * c + 1]);
       const double rmean = group_rowsum<PLg, NC>(x) * invM;
+      const double rnorm = DEFER ? group_dot<PLg, NC>(x, x) : 0.0;  // G_jj for the pivot's guard (its tile comes later)
       if (j == 0) {
         pm[i_loc] = rmean;
         pm[kRowsWG + i_loc] = xm;
+        if (DEFER) pm[2 * kRowsWG + i_loc] = rnorm;
       }
       __syncthreads();  // B1: tile and parked means complete
       EFA_BLOCKSTAMP(wave == 0 && lane == 0, 5);
-      form_gram();
+      if (!DEFER) form_gram();
       // For the block the rows change layout: wave w takes block rows 16 w .. 16 w + 15 as NJ accumulator tiles of
       // v_mfma_f64_16x16x4_f64: register v of tile J in lane l is member 16 J + (l & 15) of block row
       // 16 w + 4 v + (l >> 4).  A band's four rows are then register v = (band & 3) of ONE wave, already in the
@@ -919,6 +989,7 @@ __global__ __launch_bounds__(kGT) void k_pipe_band(const PipeArgs a) {
         for (int v = 0; v < 4; ++v) xt[J][v] = Yt[(size_t)(16 * wave + 4 * v + lr) * SP + 16 * J + lc];
       __syncthreads();  // B2: G complete; the tile region now belongs to the pivot wave's records
       barriers_left = 1;
+      if (DEFER) gram_deferred();  // (the tile region stays the parked rows until cDef says all twelve tiles are done)
       for (int b4 = 0; b4 < nbands && !bailed; b4 += 4) {
         const bool owner = (b4 >> 2) == wave;
 #pragma unroll
@@ -967,7 +1038,7 @@ __global__ __launch_bounds__(kGT) void k_pipe_band(const PipeArgs a) {
           {
             const int st = r0 + lr;  // this lane's K slice: step st
             const bool valid = lr < s1;
-            double av = s_gk[(valid ? st : r0) * kRowsWG + 16 * wave + lc].y;
+            double av = SG(valid ? st : r0)[16 * wave + lc].y;
             av = valid ? -av : 0.0;
             const double* bs = ring + (size_t)((own0 + (valid ? st : r0)) % kRingG) * TSR;
 #pragma unroll
@@ -1092,8 +1163,8 @@ bool pipeline_band_supported(int M, long R, int loc_mode) {
   const int pad = 2 * PLg * nc, ts = pad + kTrajScalars;
   const int sp = pad + ((2 - pad % 32) + 32) % 32;
   const size_t ureg = (size_t)kRowsWG * (sp > 2 * kRowsWG + kScStride + 1 ? sp : 2 * kRowsWG + kScStride + 1);
-  const size_t dbl = (size_t)kRingG * (ts + (loc_mode != 0 ? kRowsWG : 0)) + kRowsWG * kRowsWG + ureg + 2 * kRowsWG + kNBands * kBand * kBand +
-                     (loc_mode != 0 ? (size_t)kRowsWG * kRowsWG : 0);
+  const size_t dbl = (size_t)kRingG * (ts + (loc_mode != 0 ? kRowsWG : 0)) + kRowsWG * kRowsWG + ureg + 3 * kRowsWG + kNBands * kBand * kBand +
+                     (loc_mode != 0 ? (size_t)kRowsWG * kRowsWG : ((EFA_DEFER_GRAM && nc <= 13) ? (size_t)16 * kRowsWG * 2 : 0));
   return dbl * 8 + 128 <= 160 * 1024;
 }
 
