@@ -504,27 +504,53 @@ __global__ void k_obs_trig(long P, const double* __restrict__ lat, const double*
 // tw[k][row] = GC(haversine(ob_k, ob_row) / halfwidth_k): observation.py:68-83 for every pair.  Pairs clearly beyond
 // 2 halfwidths (trig-free haversine argument against s_lim, relative margin 1e-6) are 0 without evaluating anything else;
 // every other pair goes through the reference's formula.
+// Round 3: the survivors are a few per cent of the pairs but sit in four waves out of five, so evaluating them where they
+// are found made nearly every wave run the trigonometry for a handful of lanes (1.7 ms at 1e4 obs).  A wave now owns 64
+// columns for kTwRows rows: it writes the zeros (and the ones of the carried rows) at once, collects the survivors in an LDS
+// list (ballot + prefix count) and evaluates them afterwards 64 at a time.
+constexpr int kTwRows = 32;
 __global__ __launch_bounds__(256) void k_obs_taper_matrix(long P, long R, const double* __restrict__ lat,
                                                           const double* __restrict__ lon,
                                                           const double* __restrict__ hw, const double* __restrict__ tab,
                                                           double* __restrict__ tw) {
-  // one row of the table per blockIdx.y (no 64-bit division per element), columns across the threads
-  for (long k = blockIdx.y; k < P; k += gridDim.y) {
-    const double* tk = tab + k * kObTrigP;
-    const double tk0 = tk[0], tk1 = tk[1], tk2 = tk[2], tk3 = tk[3], lim = tk[4] * (1.0 + 1e-6) + 1e-13;
-    const double latk = lat[k], lonk = lon[k], hwk = hw[k];
-    for (long rr = (long)blockIdx.x * blockDim.x + threadIdx.x; rr < R; rr += (long)gridDim.x * blockDim.x) {
-      double w = 1.0;
-      if (rr < P) {
-        const double* tr = tab + rr * kObTrigP;
-        const double cc = tk0 * tr[0];
-        const double h = 0.5 * (1.0 - (cc + tk1 * tr[1])) + cc * (0.5 * (1.0 - (tk2 * tr[2] + tk3 * tr[3])));
-        w = 0.0;
-        if (!(h > lim)) w = gaspari_cohn(haversine_km(latk, lonk, lat[rr], lon[rr]), hwk);
-      }
-      tw[(size_t)k * R + rr] = w;
+  __shared__ unsigned int list[4][kTwRows * 64];  // per wave: (row in the chunk) << 6 | lane
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const long rr = ((long)blockIdx.x * 4 + wave) * 64 + lane;  // this lane's column
+  const bool col_ok = rr < R, is_ob = rr < P;
+  double c0 = 0.0, c1 = 0.0, c2 = 0.0, c3 = 0.0, latr = 0.0, lonr = 0.0;
+  if (is_ob) {
+    const double* tr = tab + rr * kObTrigP;
+    c0 = tr[0];
+    c1 = tr[1];
+    c2 = tr[2];
+    c3 = tr[3];
+    latr = lat[rr];
+    lonr = lon[rr];
+  }
+  for (long k0 = (long)blockIdx.y * kTwRows; k0 < P; k0 += (long)gridDim.y * kTwRows) {
+    int count = 0;  // wave-uniform
+    for (int i = 0; i < kTwRows; ++i) {
+      const long k = k0 + i;
+      if (k >= P) break;
+      const double* tk = tab + k * kObTrigP;   // wave-uniform loads
+      const double cc = tk[0] * c0;
+      const double h = 0.5 * (1.0 - (cc + tk[1] * c1)) + cc * (0.5 * (1.0 - (tk[2] * c2 + tk[3] * c3)));
+      const bool near = is_ob && !(h > tk[4] * (1.0 + 1e-6) + 1e-13);
+      const unsigned long long m = __ballot(near);
+      if (col_ok && !near) tw[(size_t)k * R + rr] = is_ob ? 0.0 : 1.0;
+      if (near) list[wave][count + __builtin_popcountll(m & ((1ull << lane) - 1ull))] = ((unsigned)i << 6) | (unsigned)lane;
+      count += __builtin_popcountll(m);
+    }
+    // (LDS operations of one wave are performed in order: no barrier between the list's writes and reads)
+    for (int e = lane; e < count; e += 64) {
+      const unsigned int v = list[wave][e];
+      const long k = k0 + (v >> 6);
+      const long col = rr - lane + (v & 63);
+      tw[(size_t)k * R + col] = gaspari_cohn(haversine_km(lat[k], lon[k], lat[col], lon[col]), hw[k]);
     }
   }
+  (void)latr;
+  (void)lonr;
 }
 
 template <int NC>
@@ -580,9 +606,9 @@ hipError_t launch_obs_taper_matrix(long P, long R, const double* ob_lat, const d
                                    double* trig_scratch, double* tw, hipStream_t s) {
   if (P <= 0 || R <= 0) return hipSuccess;
   hipLaunchKernelGGL(k_obs_trig, dim3((unsigned)((P + 255) / 256)), dim3(256), 0, s, P, ob_lat, ob_lon, ob_hw, trig_scratch);
-  long gx = (R + 255) / 256;
-  if (gx > 64) gx = 64;
-  const long gy = P < 65535 ? P : 65535;
+  const long gx = (R + 255) / 256;                                   // 4 waves x 64 columns per workgroup
+  long gy = (P + kTwRows - 1) / kTwRows;
+  if (gy > 4096) gy = 4096;
   hipLaunchKernelGGL(k_obs_taper_matrix, dim3((unsigned)gx, (unsigned)gy), dim3(256), 0, s, P, R, ob_lat, ob_lon, ob_hw, trig_scratch, tw);
   return hipGetLastError();
 }
