@@ -17,6 +17,8 @@
 #include "efa_internal.h"
 #include "efa_rows.h"
 
+#include <utility>
+
 namespace efa {
 namespace {
 
@@ -252,6 +254,22 @@ constexpr int kChunk = 32;  // active observations staged in LDS at a time
 #ifndef EFA_GC_RPL
 #define EFA_GC_RPL 2
 #endif
+// Rows per quad (they share every ye row read from LDS and the staging of a chunk): 2 at three waves per SIMD up to 8 chunks;
+// 4 at two waves for 9..10 chunks (65..80 members: configs[2], 64.0 -> 62.2 ms) and 3 at two waves for 11..13 chunks
+// (81..104 members: configs[3], 151 -> 141 ms); the few registers that spill are row addresses and means, saved and
+// reloaded once per group of slabs -- the loop over the observations stays spill-free (checked in the assembly).
+#ifndef EFA_GC_RPL_MID
+#define EFA_GC_RPL_MID 4
+#endif
+#ifndef EFA_GC_RPL_WIDE
+#define EFA_GC_RPL_WIDE 3
+#endif
+#ifndef EFA_GC_RPL_XWIDE
+#define EFA_GC_RPL_XWIDE 1  // at 14..16 chunks (105..128 members)
+#endif
+#ifndef EFA_GC_LANE
+#define EFA_GC_LANE 1  // members-in/members-out cycles of up to 104 members run the row-per-lane kernel (k_sweep_gc_lane)
+#endif
 #ifndef EFA_GC_COLSPLIT
 #define EFA_GC_COLSPLIT 1
 #endif
@@ -268,8 +286,13 @@ __device__ __forceinline__ double gc_dot(const double (&x)[2 * NC], const double
   return group_sum<4>(s0 + s1);
 }
 
+// waves per SIMD the register budget allows: RPL rows and one ye row of 2 NC doubles per lane, ~36 registers of everything else
+constexpr int gc_min_waves(int NC, int RPL) {
+  return (4 * NC * (RPL + 1) + 36 <= 168) ? EFA_GC_MINWAVES : (4 * NC * (RPL + 1) + 36 <= 256 || NC * (RPL + 1) <= 52) ? 2 : 1;
+}
+
 template <int NC, bool VEC, bool FUSED, int RPL>
-__global__ __launch_bounds__(256, (NC * (RPL + 1) <= 30) ? EFA_GC_MINWAVES : (NC * (RPL + 1) <= 48) ? 2 : 1) void k_sweep_gc(const GcSweepArgs a) {
+__global__ __launch_bounds__(256, gc_min_waves(NC, RPL)) void k_sweep_gc(const GcSweepArgs a) {
   constexpr int L = 4;
   constexpr int S = 2 * L * NC;  // padded ye row (doubles)
   __shared__ __align__(16) double ye_s[kChunk * S];
@@ -359,6 +382,7 @@ __global__ __launch_bounds__(256, (NC * (RPL + 1) <= 30) ? EFA_GC_MINWAVES : (NC
         lds_read_row<L, NC>(ye_s + ee * S, j, y);
 #pragma unroll
         for (int q = 0; q < RPL; ++q) {
+          if (RPL > 2 && lead0 + 4 * q >= lead_hi) continue;  // wave-uniform: this slot is beyond the last slab in every quad
           const double dot = gc_dot<NC>(x[q], y);        // :95 (a dead row holds zeros: its dot, and so its update, is exactly 0)
           xm[q] = __builtin_fma(ab.y, dot, xm[q]);       // :115, :119, :130
           const double kb = ab.x * dot;                  // :115, :119, :136
@@ -381,13 +405,163 @@ __global__ __launch_bounds__(256, (NC * (RPL + 1) <= 30) ? EFA_GC_MINWAVES : (NC
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// Row-per-lane form of the same sweep (round 3).  A lane holds one WHOLE state row (up to 104 members in registers), so the
+// dot x . ye is lane-local -- no quad butterflies -- and every fp64 instruction of the loop over the observations is a
+// multiply-add: v_fmac_f64 with a DPP row_newbcast source, which takes one multiplicand from lane l of the lane's own
+// 16-lane row.  Lane l of each row holds ye members l, 16 + l, 32 + l, ...: the whole ye vector sits in 5..7 registers
+// per lane and is read from LDS with that many 8-byte reads per wave and observation (the quad form: 10..13 16-byte reads
+// delivering the same row to each of 16 quads).  tools/dpp_fmac_probe.hip: the DPP form issues at the rate of the plain FMA.
+// A wave is 4 columns x 16 slabs (the same four columns per wave as the quad form, so the same zero-taper skipping); the last,
+// partial group of slabs of a column block is folded onto fewer waves (8 slabs: 8 columns per wave, two waves; 4 slabs: all
+// 16 columns on one wave) instead of running with dead lanes.
+// The DPP instructions are inline assembly (the compiler has no 64-bit DPP intrinsic).  Their DPP operand, ye, is written by
+// LDS reads only, never by a VALU instruction, so the "VALU write -> DPP read" hazard (which the compiler does not track
+// through inline assembly) cannot arise; tests/test_cpu_host.py checks the generated code for exactly that.
+template <int L>
+__device__ __forceinline__ void fmac_bcast(double& acc, double y, double x) {  // acc += (y of lane L of this 16-lane row) * x
+  asm volatile("v_fmac_f64_dpp %0, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf" : "+v"(acc) : "v"(y), "v"(x), "n"(L));
+}
+template <int MP, int... I>
+__device__ __forceinline__ double lane_dot(const double (&x)[MP], const double (&y)[(MP + 15) / 16], std::integer_sequence<int, I...>) {
+  double acc[4] = {0.0, 0.0, 0.0, 0.0};
+  (fmac_bcast<I % 16>(acc[I & 3], y[I / 16], x[I]), ...);
+  return (acc[0] + acc[1]) + (acc[2] + acc[3]);
+}
+template <int MP, int... I>
+__device__ __forceinline__ void lane_update(double (&x)[MP], const double (&y)[(MP + 15) / 16], double nkb, std::integer_sequence<int, I...>) {
+  (fmac_bcast<I % 16>(x[I], y[I / 16], nkb), ...);
+}
+
+constexpr int kLaneMaxMembers = 104;
+template <int MP>  // members padded to a multiple of 4
+__global__ __launch_bounds__(256, 2) void k_sweep_gc_lane(const GcSweepArgs a) {
+  constexpr int NG = (MP + 15) / 16;  // ye registers per lane
+  constexpr int YS = 16 * NG;         // padded ye row in LDS (doubles)
+  __shared__ __align__(16) double ye_s[kChunk * YS];
+  __shared__ __align__(16) double2 ab_s[kChunk * kBlkCols];
+  const int tid = threadIdx.x;
+  const int wave = tid >> 6, lane = tid & 63;
+  const long b = a.order[blockIdx.x / a.lead_split];
+  const int lead_lo = (int)(blockIdx.x % a.lead_split) * (int)a.lead_chunk;
+  const int lead_hi = (lead_lo + (int)a.lead_chunk < (int)a.n_lead) ? lead_lo + (int)a.lead_chunk : (int)a.n_lead;
+  const int M = a.M, M2 = M / 2;
+  const double rM1 = 1.0 / (double)(M - 1);
+  const long e0 = a.off[b], e1 = e0 + a.cnt[b];
+  const auto seq = std::make_integer_sequence<int, MP>{};
+
+  for (int lead0 = lead_lo; lead0 < lead_hi; lead0 += 16) {
+    // 16 slabs x 4 columns per wave; the last group of a block: the next power of two of what is left, more columns per wave
+    const int rem = lead_hi - lead0;
+    const int lg_cols = (rem > 8) ? 2 : (rem > 4) ? 3 : (rem > 2) ? 4 : (rem > 1) ? 5 : 6;
+    const int ncw = 1 << lg_cols;                 // columns per wave
+    const int cq = (lane & (ncw - 1)) + ncw * wave;
+    const int lead = lead0 + (lane >> lg_cols);
+    const long col = b * kBlkCols + cq;
+    const bool live = cq < kBlkCols && col < a.ncol && lead < lead_hi;
+    const bool any_live = __ballot(live) != 0ull;
+    const long row = (long)lead * a.ncol + col;
+    double x[MP];
+    double xm = 0.0;
+    if (live) {
+      const double2* p = reinterpret_cast<const double2*>(a.Xin + (size_t)row * M);
+      if (M == MP) {
+#pragma unroll
+        for (int i = 0; i < MP / 2; ++i) {
+          const double2 v = p[i];
+          x[2 * i] = v.x;
+          x[2 * i + 1] = v.y;
+        }
+      } else {
+#pragma unroll
+        for (int i = 0; i < MP / 2; ++i) {
+          const double2 v = (i < M2) ? p[i] : make_double2(0.0, 0.0);
+          x[2 * i] = v.x;
+          x[2 * i + 1] = v.y;
+        }
+      }
+      // prior members in: remove the ensemble mean (assimilation.py:146-147)
+      double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+#pragma unroll
+      for (int i = 0; i < MP; i += 4) {
+        s0 += x[i];
+        s1 += x[i + 1];
+        s2 += x[i + 2];
+        s3 += x[i + 3];
+      }
+      xm = ((s0 + s1) + (s2 + s3)) / (double)M;
+#pragma unroll
+      for (int i = 0; i < MP; ++i) x[i] = (i < M) ? x[i] - xm : 0.0;
+    } else {
+#pragma unroll
+      for (int i = 0; i < MP; ++i) x[i] = 0.0;
+    }
+    for (long c0 = e0; c0 < e1; c0 += kChunk) {
+      const int ne = (int)((e1 - c0 < kChunk) ? (e1 - c0) : kChunk);
+      __syncthreads();  // previous chunk fully consumed
+      {
+        constexpr int S2 = YS / 2;
+        for (int i = tid; i < ne * S2; i += 256) {
+          const int ee = i / S2, m2 = i - ee * S2;
+          const int k = a.idx[c0 + ee];
+          reinterpret_cast<double2*>(ye_s)[i] =
+              (m2 < M2) ? reinterpret_cast<const double2*>(a.Ye + (size_t)k * a.ye_stride)[m2] : make_double2(0.0, 0.0);
+        }
+      }
+      for (int i = tid; i < ne * kBlkCols; i += 256) {  // the folded gain scalars, as in k_sweep_gc
+        const double w = a.wts[(size_t)c0 * kBlkCols + i];
+        const double* ck = a.coef + (size_t)a.idx[c0 + i / kBlkCols] * kCoefStride;
+        const double g = (w * rM1) * ck[1];
+        ab_s[i] = make_double2(g * ck[2], g * ck[0]);
+      }
+      __syncthreads();
+      if (!any_live) continue;
+      for (int ee = 0; ee < ne; ++ee) {
+        double2 ab = ab_s[ee * kBlkCols + (cq & (kBlkCols - 1))];
+        if (cq >= kBlkCols) ab = make_double2(0.0, 0.0);
+        if (__ballot(ab.x != 0.0) == 0ull) continue;  // zero taper on every column of this wave
+        double y[NG];
+#pragma unroll
+        for (int c = 0; c < NG; ++c) y[c] = ye_s[ee * YS + 16 * c + (lane & 15)];
+        const double dot = lane_dot<MP>(x, y, seq);      // :95
+        xm = __builtin_fma(ab.y, dot, xm);               // :115, :119, :130
+        const double nkb = -(ab.x * dot);                // :115, :119, :136
+        lane_update<MP>(x, y, nkb, seq);                 // :141
+      }
+    }
+    if (live) {  // posterior members out (assimilation.py:168)
+      double2* p = reinterpret_cast<double2*>(a.Xout + (size_t)row * M);
+      if (M == MP) {
+#pragma unroll
+        for (int i = 0; i < MP / 2; ++i) p[i] = make_double2(x[2 * i] + xm, x[2 * i + 1] + xm);
+      } else {
+#pragma unroll
+        for (int i = 0; i < MP / 2; ++i)
+          if (i < M2) p[i] = make_double2(x[2 * i] + xm, x[2 * i + 1] + xm);
+      }
+    }
+  }
+}
+
+template <int MP>
+hipError_t gc_lane_launch_one(const GcSweepArgs& a, hipStream_t s) {
+  hipLaunchKernelGGL((k_sweep_gc_lane<MP>), dim3((unsigned)(a.nblk * a.lead_split)), dim3(256), 0, s, a);
+  return hipGetLastError();
+}
+template <int... Q>
+hipError_t gc_lane_dispatch(int q, const GcSweepArgs& a, hipStream_t s, std::integer_sequence<int, Q...>) {
+  hipError_t r = hipErrorInvalidValue;
+  (void)((q == Q + 1 ? (r = gc_lane_launch_one<4 * (Q + 1)>(a, s), true) : false) || ...);
+  return r;
+}
+
 inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
 
 template <int NC>
 hipError_t gc_launch(const GcSweepArgs& a0, hipStream_t s) {
   GcSweepArgs a = a0;
   const bool vec = (a.M % 2 == 0) && (a.ye_stride % 2 == 0) && aligned16(a.Xin) && aligned16(a.Xout) && aligned16(a.Ye);
-  constexpr int RPL = (NC <= 13) ? EFA_GC_RPL : 1;  // two rows per quad while they fit the register file
+  constexpr int RPL = (NC <= 8) ? EFA_GC_RPL : (NC <= 10) ? EFA_GC_RPL_MID : (NC <= 13) ? EFA_GC_RPL_WIDE : (NC <= 16) ? EFA_GC_RPL_XWIDE : 1;  // rows per quad while they fit the register file
   // groups of slabs per column block: whole iterations of the slab loop (4 RPL slabs), as many as it takes to give
   // every CU a dozen workgroups, at most one group per iteration
   static int cus = 0;
@@ -452,9 +626,32 @@ hipError_t launch_gc_count(long ncol, long P, const double* glat, const double* 
   return hipGetLastError();
 }
 
-hipError_t launch_sweep_gc(const GcSweepArgs& a, hipStream_t s) {
+static int device_cus() {
+  static int cus = 0;
+  if (cus == 0) {
+    int dev = 0, n = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
+    cus = n;
+  }
+  return cus;
+}
+
+hipError_t launch_sweep_gc(const GcSweepArgs& a0, hipStream_t s) {
+  const GcSweepArgs& a = a0;
   if (a.M < 2 || a.M > kMaxMembers) return hipErrorInvalidValue;
   if (a.nblk <= 0 || a.n_lead <= 0) return hipSuccess;
+  // members in -> members out with 16-byte aligned rows of up to 104 members: the row-per-lane kernel
+  if (EFA_GC_LANE && a.fused_members && a.M <= kLaneMaxMembers && (a.M % 2 == 0) && (a.ye_stride % 2 == 0) && aligned16(a.Xin) &&
+      aligned16(a.Xout) && aligned16(a.Ye)) {
+    GcSweepArgs l = a;
+    const long iters = (l.n_lead + 15) / 16;  // groups of 16 slabs; as many workgroups per block as it takes to give every CU a dozen
+    long split = (12L * device_cus() + l.nblk - 1) / l.nblk;
+    if (split > iters) split = iters;
+    if (split < 1) split = 1;
+    l.lead_chunk = ((iters + split - 1) / split) * 16;
+    l.lead_split = (int)((l.n_lead + l.lead_chunk - 1) / l.lead_chunk);
+    return gc_lane_dispatch((l.M + 3) / 4, l, s, std::make_integer_sequence<int, kLaneMaxMembers / 4>{});
+  }
   int nch = (a.M + 7) / 8;
   if (nch > 16) nch = (nch <= 20) ? 20 : (nch <= 24) ? 24 : 32;
   switch (nch) {
