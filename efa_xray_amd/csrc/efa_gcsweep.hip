@@ -428,18 +428,36 @@ __device__ __forceinline__ double lane_dot(const double (&x)[MP], const double (
   (fmac_bcast<I % 16>(acc[I & 3], y[I / 16], x[I]), ...);
   return (acc[0] + acc[1]) + (acc[2] + acc[3]);
 }
-template <int MP, int... I>
-__device__ __forceinline__ void lane_update(double (&x)[MP], const double (&y)[(MP + 15) / 16], double nkb, std::integer_sequence<int, I...>) {
-  (fmac_bcast<I % 16>(x[I], y[I / 16], nkb), ...);
+// x[16 C + i] += (ye member 16 C + i) * nkb for the members of ye register C
+template <int MP, int C, int... I>
+__device__ __forceinline__ void lane_update_group(double (&x)[MP], double yc, double nkb, std::integer_sequence<int, I...>) {
+  (fmac_bcast<I>(x[16 * C + I], yc, nkb), ...);
+}
+// The update walks the ye registers in order and re-loads each one with the NEXT active observation's members as soon as its
+// sixteen multiply-adds are issued: the LDS latency of the next ye row hides behind the rest of this update and the head of
+// the next dot, without a second set of ye registers (there are none to spare at 100 members).
+template <int MP, int C = 0>
+__device__ __forceinline__ void lane_update_prefetch(double (&x)[MP], double (&y)[(MP + 15) / 16], double nkb, const double* __restrict__ ynext) {
+  constexpr int NG = (MP + 15) / 16;
+  if constexpr (C < NG) {
+    constexpr int n = (MP - 16 * C < 16) ? MP - 16 * C : 16;
+    lane_update_group<MP, C>(x, y[C], nkb, std::make_integer_sequence<int, n>{});
+    y[C] = ynext[16 * C];
+    lane_update_prefetch<MP, C + 1>(x, y, nkb, ynext);
+  }
 }
 
 constexpr int kLaneMaxMembers = 104;
+#ifndef EFA_GC_LANE_CHUNK
+#define EFA_GC_LANE_CHUNK 32
+#endif
+constexpr int kChunkL = EFA_GC_LANE_CHUNK;  // observations staged at a time by the row-per-lane kernel (a 64-bit mask of them per wave)
 template <int MP>  // members padded to a multiple of 4
 __global__ __launch_bounds__(256, 2) void k_sweep_gc_lane(const GcSweepArgs a) {
   constexpr int NG = (MP + 15) / 16;  // ye registers per lane
   constexpr int YS = 16 * NG;         // padded ye row in LDS (doubles)
-  __shared__ __align__(16) double ye_s[kChunk * YS];
-  __shared__ __align__(16) double2 ab_s[kChunk * kBlkCols];
+  __shared__ __align__(16) double ye_s[kChunkL * YS];
+  __shared__ __align__(16) double2 ab_s[kChunkL * kBlkCols];
   const int tid = threadIdx.x;
   const int wave = tid >> 6, lane = tid & 63;
   const long b = a.order[blockIdx.x / a.lead_split];
@@ -496,8 +514,8 @@ __global__ __launch_bounds__(256, 2) void k_sweep_gc_lane(const GcSweepArgs a) {
 #pragma unroll
       for (int i = 0; i < MP; ++i) x[i] = 0.0;
     }
-    for (long c0 = e0; c0 < e1; c0 += kChunk) {
-      const int ne = (int)((e1 - c0 < kChunk) ? (e1 - c0) : kChunk);
+    for (long c0 = e0; c0 < e1; c0 += kChunkL) {
+      const int ne = (int)((e1 - c0 < kChunkL) ? (e1 - c0) : kChunkL);
       __syncthreads();  // previous chunk fully consumed
       {
         constexpr int S2 = YS / 2;
@@ -515,18 +533,33 @@ __global__ __launch_bounds__(256, 2) void k_sweep_gc_lane(const GcSweepArgs a) {
         ab_s[i] = make_double2(g * ck[2], g * ck[0]);
       }
       __syncthreads();
-      if (!any_live) continue;
-      for (int ee = 0; ee < ne; ++ee) {
-        double2 ab = ab_s[ee * kBlkCols + (cq & (kBlkCols - 1))];
-        if (cq >= kBlkCols) ab = make_double2(0.0, 0.0);
-        if (__ballot(ab.x != 0.0) == 0ull) continue;  // zero taper on every column of this wave
-        double y[NG];
+      // the staged observations with a non-zero taper on any of this wave's columns, as a bit mask (wave-uniform)
+      bool mine = false;
+      if (lane < ne && any_live) {
+        const int c_lo = ncw * wave, c_hi = (c_lo + ncw < kBlkCols) ? c_lo + ncw : kBlkCols;
+        for (int c = c_lo; c < c_hi; ++c) mine = mine || (ab_s[lane * kBlkCols + c].x != 0.0);
+      }
+      unsigned long long todo = __ballot(mine);
+      if (todo == 0ull) continue;
+      const double2* abq = ab_s + (cq & (kBlkCols - 1));  // (a lane beyond the block's 16 columns holds a zero row: whatever it reads is multiplied by 0)
+      const double* yq = ye_s + (lane & 15);
+      int ee = __builtin_ctzll(todo);
+      todo &= todo - 1;
+      double2 ab = abq[ee * kBlkCols];
+      double y[NG];
 #pragma unroll
-        for (int c = 0; c < NG; ++c) y[c] = ye_s[ee * YS + 16 * c + (lane & 15)];
+      for (int c = 0; c < NG; ++c) y[c] = yq[ee * YS + 16 * c];
+      while (true) {
+        const int en = (todo != 0ull) ? __builtin_ctzll(todo) : ee;  // the next one (after the last: itself again, harmlessly)
         const double dot = lane_dot<MP>(x, y, seq);      // :95
+        const double2 abn = abq[en * kBlkCols];
         xm = __builtin_fma(ab.y, dot, xm);               // :115, :119, :130
         const double nkb = -(ab.x * dot);                // :115, :119, :136
-        lane_update<MP>(x, y, nkb, seq);                 // :141
+        lane_update_prefetch<MP>(x, y, nkb, yq + en * YS);  // :141
+        if (todo == 0ull) break;
+        todo &= todo - 1;
+        ee = en;
+        ab = abn;
       }
     }
     if (live) {  // posterior members out (assimilation.py:168)

@@ -72,6 +72,10 @@ def test_baseline_kernels_fit_their_register_budget():
     assert find("k_sweep_gcILi10ELb1ELb1ELi4E")[".vgpr_count"] <= 256     # two
     assert find("k_sweep_gcILi13ELb1ELb1ELi3E")[".vgpr_count"] <= 256     # two
     assert find("k_contract_f32_raILi64E")[".vgpr_count"] <= 256
+    # the row-per-lane GC sweep holds a whole row per lane: two waves per SIMD up to 104 members, no spills at configs[2] / configs[3]
+    for mp in (80, 100):
+        lane = find("k_sweep_gc_laneILi%dE" % mp)
+        assert lane.get(".vgpr_spill_count", 0) == 0 and lane[".vgpr_count"] <= 256, (mp, lane[".vgpr_count"])
 
 
 def test_no_cpu_fallback_without_gpu():
@@ -364,3 +368,58 @@ def test_inflation_factors_from_a_netcdf_file(tmp_path):
         f.createVariable("t2m", "d", ("y",))[:] = np.ones(ny + 1)
     with pytest.raises(ValueError):
         Assimilation(_small_state(3), [], inflation=fn, verbose=False).inflate_state()
+
+
+def test_lane_sweep_dpp_operands_are_not_written_by_the_vector_alu_just_before():
+    """k_sweep_gc_lane's multiply-adds are inline assembly (v_fmac_f64_dpp row_newbcast), and the compiler's hazard
+    recogniser does not see through inline assembly: a VALU write of a register that one of the next two instructions
+    reads through DPP would need wait states nobody inserts.  The kernel is written so that the DPP operand (ye) only
+    ever comes from LDS reads; this checks the generated code of every instantiation."""
+    import os
+    import re
+    import subprocess
+    import tempfile
+    from efa_xray_amd import _lib
+    from _codeobj import code_objects
+    objdump = "/opt/rocm/lib/llvm/bin/llvm-objdump"
+    if not os.path.exists(objdump):
+        pytest.skip("llvm-objdump not in this image")
+    reg = re.compile(r"v\[(\d+):(\d+)\]|v(\d+)")
+
+    def regs(tok):
+        m = reg.fullmatch(tok.strip().rstrip(","))
+        if not m:
+            return set()
+        if m.group(3) is not None:
+            return {int(m.group(3))}
+        return set(range(int(m.group(1)), int(m.group(2)) + 1))
+
+    seen = 0
+    for co in code_objects(_lib.LIB_PATH):
+        if b"k_sweep_gc_lane" not in co:
+            continue
+        with tempfile.NamedTemporaryFile(suffix=".elf") as f:
+            f.write(co)
+            f.flush()
+            asm = subprocess.run([objdump, "-d", "--mcpu=gfx950", "--no-show-raw-insn", f.name], capture_output=True, text=True, check=True).stdout
+        inside = False
+        recent = []   # destination registers of the last two VALU instructions
+        for line in asm.splitlines():
+            if line.endswith(">:"):
+                inside = "k_sweep_gc_lane" in line
+                recent = []
+                continue
+            if not inside or not line.startswith("\t"):
+                continue
+            ins = line.split("//")[0].split()
+            if not ins or ins[0] == "s_nop":
+                continue
+            ops = " ".join(ins[1:]).split(",")
+            if "row_newbcast" in line:
+                seen += 1
+                src = regs(ops[1].split()[0])
+                assert src, line
+                for written in recent:
+                    assert not (src & written), "DPP operand written by the vector ALU within two instructions: " + line
+            recent = (recent + [regs(ops[0]) if ins[0].startswith("v_") and ops else set()])[-2:]
+    assert seen > 26 * 8
