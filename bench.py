@@ -364,7 +364,8 @@ def main():
         # physical minimum of ONE state-sweep launch: read + write of the member block (and, in perturbation
         # form, the mean); the fused transform / one-pass GC launches carry means in registers only
         if loc == "GC":
-            kernel = "k_sweep_gc" if ctx.get_option("gc_onepass") else "k_sweep"
+            # members in / members out with an even M <= 104: the row-per-lane form of the one-pass sweep (efa_gcsweep.hip)
+            kernel = ("k_sweep_gc_lane" if (M <= 104 and M % 2 == 0) else "k_sweep_gc") if ctx.get_option("gc_onepass") else "k_sweep"
             one_pass = bool(ctx.get_option("gc_onepass"))
             phys_bytes = 16.0 * rows * M if one_pass else 16.0 * rows * (M + 1)
         elif path_name == "transform":

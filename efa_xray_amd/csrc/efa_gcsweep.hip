@@ -17,6 +17,7 @@
 #include "efa_internal.h"
 #include "efa_rows.h"
 
+#include <cstdlib>
 #include <utility>
 
 namespace efa {
@@ -268,7 +269,7 @@ constexpr int kChunk = 32;  // active observations staged in LDS at a time
 #define EFA_GC_RPL_XWIDE 1  // at 14..16 chunks (105..128 members)
 #endif
 #ifndef EFA_GC_LANE
-#define EFA_GC_LANE 1  // members-in/members-out cycles of up to 104 members run the row-per-lane kernel (k_sweep_gc_lane)
+#define EFA_GC_LANE 1  // cycles of up to 104 members (an even number, aligned rows) run the row-per-lane kernel (k_sweep_gc_lane)
 #endif
 #ifndef EFA_GC_COLSPLIT
 #define EFA_GC_COLSPLIT 1
@@ -452,7 +453,7 @@ constexpr int kLaneMaxMembers = 104;
 #define EFA_GC_LANE_CHUNK 32
 #endif
 constexpr int kChunkL = EFA_GC_LANE_CHUNK;  // observations staged at a time by the row-per-lane kernel (a 64-bit mask of them per wave)
-template <int MP>  // members padded to a multiple of 4
+template <int MP, bool FUSED>  // members padded to a multiple of 4; FUSED: prior members in, posterior members out
 __global__ __launch_bounds__(256, 2) void k_sweep_gc_lane(const GcSweepArgs a) {
   constexpr int NG = (MP + 15) / 16;  // ye registers per lane
   constexpr int YS = 16 * NG;         // padded ye row in LDS (doubles)
@@ -460,9 +461,16 @@ __global__ __launch_bounds__(256, 2) void k_sweep_gc_lane(const GcSweepArgs a) {
   __shared__ __align__(16) double2 ab_s[kChunkL * kBlkCols];
   const int tid = threadIdx.x;
   const int wave = tid >> 6, lane = tid & 63;
-  const long b = a.order[blockIdx.x / a.lead_split];
-  const int lead_lo = (int)(blockIdx.x % a.lead_split) * (int)a.lead_chunk;
-  const int lead_hi = (lead_lo + (int)a.lead_chunk < (int)a.n_lead) ? lead_lo + (int)a.lead_chunk : (int)a.n_lead;
+  // One workgroup per (column block, group of 16 slabs), blocks longest list first, a block's groups next to each other (its
+  // list stays in L2) but starting at a different group from block to block.  (The list is staged once per group of slabs
+  // whichever workgroup takes it, so the fine split costs nothing.  The hardware deals consecutive workgroups to the eight
+  // XCDs in turn: with several groups per workgroup and unequal parts, the larger parts of every block landed on the same
+  // XCDs -- measured as up to 25 % imbalance on a polar shard; all blocks' first groups, then all second groups, ... is even
+  // but 2.5 % slower on the whole grid, the lists leaving L2 between a block's groups.)
+  const long pos = blockIdx.x / a.lead_split;
+  const long b = a.order[pos];
+  const int lead_lo = 16 * (int)((blockIdx.x % a.lead_split + pos) % a.lead_split);
+  const int lead_hi = (lead_lo + 16 < (int)a.n_lead) ? lead_lo + 16 : (int)a.n_lead;
   const int M = a.M, M2 = M / 2;
   const double rM1 = 1.0 / (double)(M - 1);
   const long e0 = a.off[b], e1 = e0 + a.cnt[b];
@@ -498,18 +506,21 @@ __global__ __launch_bounds__(256, 2) void k_sweep_gc_lane(const GcSweepArgs a) {
           x[2 * i + 1] = v.y;
         }
       }
-      // prior members in: remove the ensemble mean (assimilation.py:146-147)
-      double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+      if (FUSED) {  // prior members in: remove the ensemble mean (assimilation.py:146-147)
+        double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
 #pragma unroll
-      for (int i = 0; i < MP; i += 4) {
-        s0 += x[i];
-        s1 += x[i + 1];
-        s2 += x[i + 2];
-        s3 += x[i + 3];
+        for (int i = 0; i < MP; i += 4) {
+          s0 += x[i];
+          s1 += x[i + 1];
+          s2 += x[i + 2];
+          s3 += x[i + 3];
+        }
+        xm = ((s0 + s1) + (s2 + s3)) / (double)M;
+#pragma unroll
+        for (int i = 0; i < MP; ++i) x[i] = (i < M) ? x[i] - xm : 0.0;
+      } else {
+        xm = a.xin[row];
       }
-      xm = ((s0 + s1) + (s2 + s3)) / (double)M;
-#pragma unroll
-      for (int i = 0; i < MP; ++i) x[i] = (i < M) ? x[i] - xm : 0.0;
     } else {
 #pragma unroll
       for (int i = 0; i < MP; ++i) x[i] = 0.0;
@@ -562,23 +573,26 @@ __global__ __launch_bounds__(256, 2) void k_sweep_gc_lane(const GcSweepArgs a) {
         ab = abn;
       }
     }
-    if (live) {  // posterior members out (assimilation.py:168)
+    if (live) {  // posterior members out (assimilation.py:168), or perturbations and mean
       double2* p = reinterpret_cast<double2*>(a.Xout + (size_t)row * M);
+      const double add = FUSED ? xm : 0.0;
       if (M == MP) {
 #pragma unroll
-        for (int i = 0; i < MP / 2; ++i) p[i] = make_double2(x[2 * i] + xm, x[2 * i + 1] + xm);
+        for (int i = 0; i < MP / 2; ++i) p[i] = make_double2(x[2 * i] + add, x[2 * i + 1] + add);
       } else {
 #pragma unroll
         for (int i = 0; i < MP / 2; ++i)
-          if (i < M2) p[i] = make_double2(x[2 * i] + xm, x[2 * i + 1] + xm);
+          if (i < M2) p[i] = make_double2(x[2 * i] + add, x[2 * i + 1] + add);
       }
+      if (!FUSED) a.xout[row] = xm;
     }
   }
 }
 
 template <int MP>
 hipError_t gc_lane_launch_one(const GcSweepArgs& a, hipStream_t s) {
-  hipLaunchKernelGGL((k_sweep_gc_lane<MP>), dim3((unsigned)(a.nblk * a.lead_split)), dim3(256), 0, s, a);
+  if (a.fused_members) hipLaunchKernelGGL((k_sweep_gc_lane<MP, true>), dim3((unsigned)(a.nblk * a.lead_split)), dim3(256), 0, s, a);
+  else hipLaunchKernelGGL((k_sweep_gc_lane<MP, false>), dim3((unsigned)(a.nblk * a.lead_split)), dim3(256), 0, s, a);
   return hipGetLastError();
 }
 template <int... Q>
@@ -673,16 +687,12 @@ hipError_t launch_sweep_gc(const GcSweepArgs& a0, hipStream_t s) {
   const GcSweepArgs& a = a0;
   if (a.M < 2 || a.M > kMaxMembers) return hipErrorInvalidValue;
   if (a.nblk <= 0 || a.n_lead <= 0) return hipSuccess;
-  // members in -> members out with 16-byte aligned rows of up to 104 members: the row-per-lane kernel
-  if (EFA_GC_LANE && a.fused_members && a.M <= kLaneMaxMembers && (a.M % 2 == 0) && (a.ye_stride % 2 == 0) && aligned16(a.Xin) &&
+  // 16-byte aligned rows of up to 104 members (an even number of them): the row-per-lane kernel
+  if (EFA_GC_LANE && a.M <= kLaneMaxMembers && (a.M % 2 == 0) && (a.ye_stride % 2 == 0) && aligned16(a.Xin) &&
       aligned16(a.Xout) && aligned16(a.Ye)) {
     GcSweepArgs l = a;
-    const long iters = (l.n_lead + 15) / 16;  // groups of 16 slabs; as many workgroups per block as it takes to give every CU a dozen
-    long split = (12L * device_cus() + l.nblk - 1) / l.nblk;
-    if (split > iters) split = iters;
-    if (split < 1) split = 1;
-    l.lead_chunk = ((iters + split - 1) / split) * 16;
-    l.lead_split = (int)((l.n_lead + l.lead_chunk - 1) / l.lead_chunk);
+    l.lead_split = (int)((l.n_lead + 15) / 16);  // groups of 16 slabs: one workgroup each
+    l.lead_chunk = 16;
     return gc_lane_dispatch((l.M + 3) / 4, l, s, std::make_integer_sequence<int, kLaneMaxMembers / 4>{});
   }
   int nch = (a.M + 7) / 8;
