@@ -872,11 +872,15 @@ def test_gc_goldens_per_batch_table_path(name):
 
 @pytest.mark.parametrize("N,M,P,ncol", [(3 * 48 * 64, 40, 300, 48 * 64), (5 * 700, 80, 150, 700), (2 * 1000, 100, 64, 1000),
                                         (7 * 333, 2, 40, 333), (1 * 257, 128, 33, 257), (6 * 64, 6, 20, 64),
-                                        (2 * 300, 130, 40, 300), (3 * 200, 200, 30, 200), (1 * 100, 256, 20, 100)])
+                                        (2 * 300, 130, 40, 300), (3 * 200, 200, 30, 200), (1 * 100, 256, 20, 100),
+                                        # the row-per-lane kernel: whole groups of 16 slabs plus a partial one of 5, 1, 10, 3, 2 slabs;
+                                        # member counts that are not a multiple of 4 (padded lanes) and the largest it takes (104)
+                                        (37 * 100, 98, 40, 100), (17 * 50, 102, 30, 50), (26 * 40, 104, 25, 40), (19 * 33, 10, 30, 33),
+                                        (18 * 20, 64, 20, 20), (32 * 17, 50, 20, 17)])
 def test_one_pass_gc_sweep_vs_oracle_ragged_shapes(N, M, P, ncol):
     """The one-pass localised sweep against the oracle, in perturbation form and as prior members -> posterior
     members, on shapes whose column count is not a multiple of the 16-column block and whose slab count is not a
-    multiple of the 4-slab group; zero-taper rows bit-unchanged."""
+    multiple of the slab group (4 RPL slabs in the quad form, 16 in the row-per-lane form); zero-taper rows bit-unchanged."""
     c = _random_case(900 + N + M + P, N, M, P, True, ncol=ncol)
     c["hw"][:] = np.random.default_rng(M).uniform(300, 3000, P)
     xam, Xap, diag = _run_oracle(c)
