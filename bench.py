@@ -257,6 +257,42 @@ def measure(args, wl, strong, world, rank, eng, dist, torch, seed, balance=True)
                 kind=ctx.get_option("phase_a_kind"))
 
 
+def init_library_comm(eng, rank, world, dist, torch, timeout_s=120.0):
+    """The library's own RCCL communicator (efa_comm_init) with one checked all-reduce, created in a helper thread so that a
+    communicator that cannot be brought up on this node (it has only ever run at world size 1 where this was built) costs a
+    timeout, not the run: the ranks then agree (one MIN all-reduce through torch.distributed) to use torch.distributed's
+    own RCCL all-reduce for the exchange step instead.  Both are RCCL on the GPUs; which one ran is reported in `collective`."""
+    import threading
+    ok = [False]
+    err = [None]
+
+    def bring_up():
+        try:
+            eng.init_comm(rank, world)
+            probe = torch.full((1024,), float(rank + 1), dtype=torch.float64, device=eng.device)
+            eng.all_reduce_sum(probe)
+            torch.cuda.synchronize()
+            ok[0] = bool((probe == world * (world + 1) / 2.0).all().item())
+            if not ok[0]:
+                err[0] = "probe all-reduce returned %r" % probe[0].item()
+        except Exception as e:          # noqa: BLE001 -- any failure means: use the other collective
+            err[0] = repr(e)
+
+    t = threading.Thread(target=bring_up, daemon=True)
+    t.start()
+    t.join(timeout_s)
+    if t.is_alive():
+        err[0] = "efa_comm_init did not return within %.0f s" % timeout_s
+    flag = torch.tensor([1.0 if (ok[0] and not t.is_alive()) else 0.0], device=eng.device)
+    dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+    if flag.item() == 1.0:
+        return "efa_allreduce_sum_dev (RCCL ncclAllReduce sum f64 on the context stream)"
+    eng.has_comm = False
+    if err[0] is not None:
+        sys.stderr.write("[bench] rank %d: library communicator unavailable (%s); using torch.distributed all_reduce\n" % (rank, err[0]))
+    return "torch.distributed all_reduce (RCCL) -- the library's own communicator could not be brought up on this node"
+
+
 def main():
     args = parse_args()
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -312,8 +348,7 @@ def main():
     ctx.set_option("timing", 1)
     collective = "none (one rank)"
     if world > 1 and not rehearse:
-        eng.init_comm(rank, world)          # the library's own RCCL communicator (efa_comm_init)
-        collective = "efa_allreduce_sum_dev (RCCL ncclAllReduce sum f64 on the context stream)"
+        collective = init_library_comm(eng, rank, world, dist, torch)
     elif world > 1:
         collective = "torch.distributed gloo (rehearsal)"
 
@@ -468,8 +503,14 @@ def main():
             X = post = r = None
             torch.cuda.empty_cache()
             out["host_api"] = host_api_timing(local_rank)
-        print(json.dumps(out))
+        print(json.dumps(out), flush=True)
     if world > 1:
+        dist.barrier()
+        if "could not be brought up" in collective:
+            # a helper thread may still sit inside the communicator's bring-up: leave without running its destructors
+            sys.stdout.flush()
+            sys.stderr.flush()
+            os._exit(0)
         dist.destroy_process_group()
     ctx.close()
 

@@ -228,3 +228,59 @@ def test_cost_balanced_column_bounds_on_a_global_grid():
     assert balanced_column_bounds(np.zeros(1), 10, 3) == column_bounds(10, 3)
     b0 = balanced_column_bounds(np.zeros(8), 128, 4)
     assert b0 == [(0, 32), (32, 64), (64, 96), (96, 128)]
+
+
+class _CommEngine:
+    """Stand-in for HipEngine in bench.init_library_comm: the communicator comes up on rank 0 only."""
+    def __init__(self, rank):
+        self.device = torch.device("cpu")
+        self.has_comm = False
+        self.rank = rank
+
+    def init_comm(self, rank, world):
+        if rank != 0:
+            raise RuntimeError("no communicator on this rank")
+        self.has_comm = True
+
+    def all_reduce_sum(self, t):
+        t.fill_(3.0)     # what a 2-rank sum of rank + 1 gives
+        return t
+
+
+def _comm_worker(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import bench
+
+        class _T:                      # torch with a synchronize() that works without a GPU
+            def __getattr__(self, n):
+                return getattr(torch, n)
+            class cuda:                # noqa: E301
+                @staticmethod
+                def synchronize():
+                    pass
+        eng = _CommEngine(rank)
+        how = bench.init_library_comm(eng, rank, world, dist, _T(), timeout_s=30.0)
+        q.put((rank, how, eng.has_comm))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_bench_falls_back_to_torch_all_reduce_when_one_rank_has_no_library_communicator():
+    """bench.py, N > 1: the ranks agree on ONE collective -- the library's own RCCL communicator only if it came up
+    (and passed a probe all-reduce) on every rank, otherwise torch.distributed's all-reduce everywhere."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_comm_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = sorted(q.get(timeout=120) for _ in range(2))
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    for rank, how, has_comm in got:
+        assert how.startswith("torch.distributed all_reduce") and not has_comm, (rank, how, has_comm)
