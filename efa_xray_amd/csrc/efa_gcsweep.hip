@@ -176,32 +176,43 @@ __global__ __launch_bounds__(64 * kBuildWaves) void k_gc_build(long ncol, long n
                                                                const long* __restrict__ off, int* __restrict__ idx,
                                                                double* __restrict__ wts,
                                                                unsigned long long* __restrict__ npairs) {
-  const int lane = threadIdx.x & 63;
-  const long b = (long)blockIdx.x * kBuildWaves + (threadIdx.x >> 6);
-  if (b >= nblk) return;
+  // Round 3: two steps per 64 observations.  (1) lane <-> observation: the latitude candidates run the trig-free rejection
+  // against each of the block's columns (their cos / sin from LDS) and the survivors -- observations within reach of at least one
+  // column -- go into a small per-wave queue in ascending order; (2) lane <-> (column, one of four queued observations): the
+  // reference's formula, now with nearly every lane busy.  Before, (2) ran on the latitude candidates directly and a step of
+  // four candidates paid for the trigonometry whenever any of its 64 pairs survived (about half of the steps, a few lanes each).
+  __shared__ double coltrig[kBuildWaves][kBlkCols][4];
+  __shared__ int queue[kBuildWaves][128];
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const long b = (long)blockIdx.x * kBuildWaves + wv;
+  if (b >= nblk) return;  // (no workgroup barrier below)
   const int c = lane & 15, o = lane >> 4;
   const long col = b * kBlkCols + c;
   const bool col_ok = col < ncol;
+  const int ncols_live = (int)((ncol - b * kBlkCols < kBlkCols) ? ncol - b * kBlkCols : kBlkCols);
   const double la = col_ok ? glat[col] : 0.0, lo = col_ok ? glon[col] : 0.0;
   const double cg = cos(radians(la)), sg = sin(radians(la)), cl = cos(radians(lo)), sl = sin(radians(lo));
+  if (lane < kBlkCols) {
+    coltrig[wv][lane][0] = cg;
+    coltrig[wv][lane][1] = sg;
+    coltrig[wv][lane][2] = cl;
+    coltrig[wv][lane][3] = sl;
+  }
+  __builtin_amdgcn_wave_barrier();  // (one wave's LDS operations complete in order)
   double la_lo, la_hi;
   block_lat_range(col_ok, la, la_lo, la_hi);
   const long first = COUNT_ONLY ? 0 : off[b];
   long running = first;
   long pairs = 0;  // (column, observation) pairs with a non-zero taper: SURVEY.md 8d's bytes_touched
-  for (long k0 = 0; k0 < P; k0 += 64) {
-    unsigned long long cand = lat_candidates(k0 + lane, P, la_lo, la_hi, ob_lat, ob_hw, coef);
-    while (cand != 0ull) {  // four candidates per step, ascending
-      int kb[4];
-#pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        kb[i] = (cand != 0ull) ? (int)__builtin_ctzll(cand) : -1;
-        if (cand != 0ull) cand &= cand - 1;
-      }
-      const int bit = (o == 0) ? kb[0] : (o == 1) ? kb[1] : (o == 2) ? kb[2] : kb[3];
-      const long k = k0 + bit;
+  int qh = 0, qn = 0;  // the queue's head and length (wave-uniform)
+  auto drain = [&](bool all) {
+    while (qn >= 4 || (all && qn > 0)) {  // four queued observations per step, ascending
+      const int take = qn < 4 ? qn : 4;
+      const long k = (o < take) ? queue[wv][(qh + o) & 127] : -1;
+      qh += take;
+      qn -= take;
       double w = 0.0;
-      if (bit >= 0 && col_ok) {
+      if (k >= 0 && col_ok) {
         const double* t = obtrig + k * kObTrig;
         const double2 tp = *reinterpret_cast<const double2*>(t), tl = *reinterpret_cast<const double2*>(t + 2);
         const double cc = tp.x * cg;
@@ -228,7 +239,29 @@ __global__ __launch_bounds__(64 * kBuildWaves) void k_gc_build(long ncol, long n
       }
       running += total;
     }
+  };
+  for (long k0 = 0; k0 < P; k0 += 64) {
+    const unsigned long long cand = lat_candidates(k0 + lane, P, la_lo, la_hi, ob_lat, ob_hw, coef);
+    if (cand == 0ull) continue;
+    bool surv = false;
+    if ((cand >> lane) & 1ull) {
+      const double* t = obtrig + (k0 + lane) * kObTrig;
+      const double2 tp = *reinterpret_cast<const double2*>(t), tl = *reinterpret_cast<const double2*>(t + 2);
+      const double lim = t[4] * (1.0 + 1e-6) + 1e-13;
+      for (int c2 = 0; c2 < ncols_live; ++c2) {
+        const double cc = tp.x * coltrig[wv][c2][0];
+        const double h = 0.5 * (1.0 - (cc + tp.y * coltrig[wv][c2][1])) + cc * (0.5 * (1.0 - (tl.x * coltrig[wv][c2][2] + tl.y * coltrig[wv][c2][3])));
+        surv = surv || !(h > lim);
+      }
+    }
+    const unsigned long long sm = __ballot(surv);
+    if (sm == 0ull) continue;
+    if (surv) queue[wv][(qh + qn + __builtin_popcountll(sm & ((1ull << lane) - 1ull))) & 127] = (int)(k0 + lane);
+    qn += __builtin_popcountll(sm);
+    __builtin_amdgcn_wave_barrier();
+    drain(false);
   }
+  drain(true);
   if (lane == 0) {
     cnt[b] = (int)(running - first);
     if (COUNT_ONLY && idx) idx[b] = (int)pairs;  // counting pass: the block's (column, observation) pairs
