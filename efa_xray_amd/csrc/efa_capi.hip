@@ -146,7 +146,7 @@ struct efa_ctx {
   PinBuf pin_in, pin_out;    // their pinned host images: one H2D and one D2H per call
   PinBuf pin_fs;             // pinned image of the forward-operator stencil
   hipEvent_t ev_fs = nullptr;  // its last host-to-device copy
-  DevBuf ob_val, ob_err, ob_asm, ob_lat, ob_lon, ob_hw, ob_errsq;  // device copies [P] ([P][2] the last)
+  DevBuf ob_val, ob_err, ob_asm, ob_lat, ob_lon, ob_hw, ob_errsq;  // device copies [P] ([P][4] the last)
   DevBuf d_prior_mean, d_prior_var, d_post_mean, d_post_var, d_assimilated;
   DevBuf Yw, ymw;  // obs block workspace [(P+M)][M], [(P+M)]
   DevBuf win_Y, win_m;  // rows of one Phase-A window + the transform rows (only when P exceeds one persistent launch)
@@ -257,7 +257,7 @@ int obs_phase(efa_ctx* c, int M, long P, double* ym_dev, double* Yp_dev, const d
   {
     const bool gc = loc_mode == EFA_LOC_GC;
     const size_t slot = ((size_t)P * sizeof(double) + 255) & ~(size_t)255;
-    const size_t total = 8 * slot;  // ... | {error, sqrt(error)} pairs: the band leader's per-ob constants, fetched by scalar loads
+    const size_t total = 10 * slot;  // ... | {error, sqrt(error), assimilate (1.0 / 0.0), 0}: the band leader's per-ob constants, fetched with wave-uniform loads
     EFA_TRY(c->ob_pack.reserve(total));
     EFA_TRY(c->pin_in.reserve(total));
     char* hb = static_cast<char*>(c->pin_in.p);
@@ -273,11 +273,13 @@ int obs_phase(efa_ctx* c, int M, long P, double* ym_dev, double* Yp_dev, const d
     {
       double* ec = reinterpret_cast<double*>(hb + 6 * slot);
       for (long k = 0; k < P; ++k) {
-        ec[2 * k] = ob_error[k];
-        ec[2 * k + 1] = std::sqrt(ob_error[k]);
+        ec[4 * k] = ob_error[k];
+        ec[4 * k + 1] = std::sqrt(ob_error[k]);
+        ec[4 * k + 2] = ob_assim[k] ? 1.0 : 0.0;
+        ec[4 * k + 3] = 0.0;
       }
     }
-    c->ob_errsq.carve(db + 6 * slot, 2 * slot);
+    c->ob_errsq.carve(db + 6 * slot, 4 * slot);
     c->ob_val.carve(db, slot);
     c->ob_err.carve(db + slot, slot);
     c->ob_lat.carve(db + 2 * slot, slot);
@@ -288,7 +290,7 @@ int obs_phase(efa_ctx* c, int M, long P, double* ym_dev, double* Yp_dev, const d
       EFA_HIP(hipMemcpyAsync(db, hb, total, hipMemcpyHostToDevice, c->stream));
     } else {
       EFA_HIP(hipMemcpyAsync(db, hb, 2 * slot, hipMemcpyHostToDevice, c->stream));
-      EFA_HIP(hipMemcpyAsync(db + 5 * slot, hb + 5 * slot, 3 * slot, hipMemcpyHostToDevice, c->stream));
+      EFA_HIP(hipMemcpyAsync(db + 5 * slot, hb + 5 * slot, 5 * slot, hipMemcpyHostToDevice, c->stream));
     }
   }
   EFA_TRY(c->Ye_rec.reserve((size_t)P * M * sizeof(double)));
@@ -435,7 +437,7 @@ int obs_phase(efa_ctx* c, int M, long P, double* ym_dev, double* Yp_dev, const d
       pa.ob_value = c->ob_val.as<double>() + w0;
       pa.ob_error = c->ob_err.as<double>() + w0;
       pa.ob_assim = c->ob_asm.as<uint8_t>() + w0;
-      pa.ob_errsq = c->ob_errsq.as<double>() + 2 * w0;
+      pa.ob_errsq = c->ob_errsq.as<double>() + 4 * w0;
       pa.loc_mode = loc_mode;
       pa.tw = nullptr;
       if (loc_mode == EFA_LOC_GC) {
@@ -955,6 +957,7 @@ int efa_ctx_get_option(efa_ctx* c, const char* key, long* value) {
   else if (!strcmp(key, "cu_count")) *value = c->cu_count;
   else if (!strcmp(key, "phase_a_kind")) *value = c->phase_a_kind;
   else if (!strcmp(key, "pipe_dbg_addr")) *value = (long)reinterpret_cast<uintptr_t>(c->dbg.p);
+  else if (!strcmp(key, "traj_addr")) *value = (long)reinterpret_cast<uintptr_t>(c->traj.p);  // (diagnostic tools only)
   else if (!strcmp(key, "traj_addr")) *value = (long)reinterpret_cast<uintptr_t>(c->traj.p);  // diagnostic
   else if (!strcmp(key, "device")) *value = c->device;
   else return fail(EFA_ERR_INVALID, "unknown option '%s'", key);

@@ -91,7 +91,7 @@ struct PipeArgs {
   const double* ob_value;  // device [P]
   const double* ob_error;
   const uint8_t* ob_assim;
-  const double* ob_errsq;  // device [P][2]: {error, sqrt(error)} (the band leader reads them with scalar loads)
+  const double* ob_errsq;  // device [P][4]: {error, sqrt(error), assimilate (1.0 / 0.0), 0} (the band leader reads them with wave-uniform loads)
   int loc_mode;
   const double* tw;  // GC: dense obs-obs taper [P][R] (row k = ob k against every row); else null
   unsigned long long* traj;  // [P][traj_stride(M)] sentinel-filled

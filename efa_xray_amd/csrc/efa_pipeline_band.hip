@@ -269,6 +269,7 @@ __global__ __launch_bounds__(kGT) void k_pipe_band(const PipeArgs a) {
         if (g_ctl(&ctl[cBail]) != 0) return false;
         budget -= 16;
         if (budget <= 0 || EFA_TIMED_OUT()) {
+          EFA_PS(if (a.dbg != nullptr && lane == 0) { u64* d = a.dbg + (size_t)(32 + wave) * 8; d[0] = 1000 + (u64)(word - ctl); d[1] = (u64)thr; d[2] = (u64)g_ctl(word); d[3] = (u64)own0; })
           give_up();
           return false;
         }
@@ -444,77 +445,88 @@ __global__ __launch_bounds__(kGT) void k_pipe_band(const PipeArgs a) {
       double xmv = pm[kRowsWG + lane];
       const bool f_ob = lane < nb;
       const double val_l = f_ob ? a.ob_value[own0 + lane] : 0.0;
-      const double2 ec_l = f_ob ? *reinterpret_cast<const double2*>(a.ob_errsq + 2 * (own0 + lane)) : make_double2(1.0, 1.0);
-      const u64 asm_mask = __ballot(f_ob ? (a.ob_assim[own0 + lane] != 0) : false);
-      double l_xm = 0.0;
+      const double2 ec_l = f_ob ? *reinterpret_cast<const double2*>(a.ob_errsq + 4 * (own0 + lane)) : make_double2(1.0, 1.0);
+      const bool my_asm = f_ob ? (a.ob_assim[own0 + lane] != 0) : false;
+      // The pivot wave's two guards are kept HERE, off the serial chain (this wave reads every step's G_kk anyway; a tripped
+      // guard abandons the launch, nothing produced meanwhile is used, so it does not matter that it trips a band later).
+      // Cancellation: an assimilated pivot whose G_kk fell below 1e-3 of its value at block start.
+      // Centring: np.var re-centres (:69), var = G_kk / M - mean^2; the rows are mean-removed perturbations (assimilation.py:47,
+      // :147), their means are rounding residue and mean^2 changes no bit of var or kdenom, so the chain does not carry the
+      // means; a block whose pivot rows are NOT centred (mean^2 above 1e-22 of var or of the error variance) goes to the
+      // vector-chain kernel, which computes np.var as written.
+      const double gjj0 = DEFER ? pm[2 * kRowsWG + lane] : G_s[lane * kRowsWG + lane];  // |y_j|^2 at block start
+      const double thr = my_asm ? 1e-3 * gjj0 : -1.0;
+      bool bad = f_ob && !(pm[lane] * pm[lane] <= 1e-22 * fmin(ec_l.x, gjj0 * invM));  // pm[0][j]: the member mean of row j
+      double l_xm = 0.0, l_innov = 0.0;
       double l_var = 0.0, l_rd = 0.0, l_be = 0.0;  // this lane's ob: prior variance, 1/kdenom, beta -- from G_kk at its step
+      // Round 3: the ye rows of a record go to global memory straight from the vector wave that forms them (below, "owner"), so
+      // this wave stores only the record's four scalars -- and those hang on the pivot's step records alone, not on YE: it runs
+      // right behind the pivot (cSReady) instead of behind the YE tiles, touches the ring no more, and publishes a band's scalars
+      // with four stores from the band's own lanes.  (The followers validate every word of a record by itself, so its two parts
+      // may arrive in either order.)  Before, this wave read every ye row back from the ring and stored it: as slow as the pivot,
+      // and its backlog was the first 4-7 k cycles of every hand-over.
+      if (lane == 0) g_ctl_set(&ctl[cFwd], 0x7fffffff);  // (not a consumer of the ring any more)
+      u64* const rec_l = a.traj + (size_t)(own0 + (f_ob ? lane : 0)) * TS + PAD;  // this lane's ob: its record's scalars
       for (int b = 0; b < nbands && !failed; ++b) {
-        // the band's ye rows are in the ring once every vector wave has added its tiles (4 per band)
-        if (!wait_gt(&ctl[cYe], 4 * (b + 1) - 1, true)) {
+        const int s1 = (nb - kBand * b < kBand) ? nb - kBand * b : kBand;
+        if (!wait_gt(&ctl[cSReady], kBand * b + s1 - 1, true)) {  // the pivot has recorded the band's steps
           failed = true;
           break;
         }
-        const int s1 = (nb - kBand * b < kBand) ? nb - kBand * b : kBand;
+        const bool mine = (lane >> 2) == b;  // kBand == 4
         {  // the band's obs, one per lane: the scalars the pivot wave used at their steps, recomputed from the same G_kk
           const double Gkk = SG(lane & 63)[lane].x;
           double rd, be;
           gain_scalars(Gkk, invM, ec_l.x, ec_l.y, rd, be);
-          const bool mine = (lane >> 2) == b;  // kBand == 4
+          bad = bad || (mine && f_ob && !(Gkk > thr));  // (a block's last band may be partial)
           l_rd = mine ? rd : l_rd;
           l_be = mine ? be : l_be;
           l_var = mine ? Gkk * invM : l_var;                                   // np.var, ddof = 0 (:69, :70): the rows are centred
         }
-        // Every LDS operand of the band first (ONE round trip for its up to four records: the forwarder used to pay three
-        // per record and was as slow as the pivot wave), then the serial mean chain of its steps, then the stores.
+        // Every LDS operand of the band first (one round trip for its up to four records), then the serial mean chain
         double2 gk4[kBand];
-        double yv[kBand][EPL], tw4[kBand];
+        double tw4[kBand];
 #pragma unroll
         for (int s = 0; s < kBand; ++s) {
           const int st = kBand * b + ((s < s1) ? s : 0);
-          const double* slot = ring + (size_t)((own0 + st) % kRingG) * TSR;
           gk4[s] = SG(st)[lane];                                  // G_kj, kb_j of this lane's row
           tw4[s] = GC ? tw_s[st * kRowsWG + lane] : 1.0;
-#pragma unroll
-          for (int e = 0; e < EPL; ++e) yv[s][e] = slot[(lane + 64 * e < PAD) ? lane + 64 * e : 0];
         }
+        const double rd_a = my_asm ? l_rd : 0.0;                  // :74: an ob that is not assimilated moves no mean
 #pragma unroll
         for (int s = 0; s < kBand; ++s) {
           if (s >= s1) break;  // wave-uniform
           const int st = kBand * b + s;
-          const long f = own0 + st;
-          const double rden = rl(l_rd, st), beta_k = rl(l_be, st);
-          const bool act = ((asm_mask >> st) & 1) != 0;
-          const double xmk = rl(xmv, st);
-          const double innov = rl(val_l, st) - xmk;                            // :85
+          const double dv = val_l - xmv;                                       // :85 in the ob's own lane
+          const double innov = rl(dv, st);
+          const double rden_a = rl(rd_a, st);
           double kc = gk4[s].x * rM1;                                          // :95
           if (GC) kc = tw4[s] * kc;                                            // :115
-          const double km = act ? kc * rden : 0.0;                             // :119
+          const double km = kc * rden_a;                                       // :119
+          l_xm = (lane == st) ? xmv : l_xm;                                    // this lane's ob: its prior mean (:66)
+          l_innov = (lane == st) ? dv : l_innov;
           xmv = xmv + km * innov;                                              // :130
-          l_xm = (lane == st) ? xmk : l_xm;                                    // this lane's ob: its prior mean (:66)
-          // record = ye, then the four scalars the followers read: rden, beta, innov, active
-          u64* rec = a.traj + (size_t)f * TS;
-          const double actv = act ? 1.0 : 0.0;
-#pragma unroll
-          for (int e = 0; e < EPL; ++e) {
-            const int idx = lane + 64 * e;
-            if (64 * (e + 1) <= PAD) {
-              g_traj_store(rec + idx, yv[s][e]);
-            } else if (idx < TS) {
-              // >= 0: one of the scalars (values of this wave: no hand-off between lanes).  The followers read two:
-              // c = beta / ((M-1) kdenom), 0 for an ob that is not assimilated, and m = innov / ((M-1) kdenom):
-              // kb_j = w c (y_j . ye), xm_j += w m (y_j . ye)   (:95, :115, :119, :130, :136 folded once per ob)
-              const int sj = idx - PAD;
-              const double cf = act ? (beta_k * rden) * rM1 : 0.0, mf = (rden * rM1) * innov;
-              double v = yv[s][e];
-              v = (sj == 0) ? cf : v;
-              v = (sj == 1) ? mf : v;
-              v = (sj == 2) ? innov : v;
-              v = (sj >= 3) ? actv : v;
-              g_traj_store(rec + idx, v);
-            }
-          }
         }
-        if (lane == 0) g_ctl_set(&ctl[cFwd], (int)(own0 + kBand * b + s1 - 1));  // ring slots up to here are free again
+        // the records' scalars, from the band's own lanes.  The followers read two: c = beta / ((M-1) kdenom), 0 for an ob that
+        // is not assimilated, and m = innov / ((M-1) kdenom): kb_j = w c (y_j . ye), xm_j += w m (y_j . ye)
+        // (:95, :115, :119, :130, :136 folded once per ob); then innov and the assimilate flag
+        if (mine && f_ob) {
+          const double cf = my_asm ? (l_be * l_rd) * rM1 : 0.0, mf = (l_rd * rM1) * l_innov;
+          g_traj_store(rec_l + 0, cf);
+          g_traj_store(rec_l + 1, mf);
+          g_traj_store(rec_l + 2, l_innov);
+          const double actv = my_asm ? 1.0 : 0.0;
+#pragma unroll
+          for (int sj = 3; sj < TS - PAD; ++sj) g_traj_store(rec_l + sj, actv);  // (the followers wait for every word of a record)
+        }
+      }
+      // (not when the launch is being abandoned anyway: then this block may have run on rows that were never parked)
+      if (!failed && __ballot(bad) != 0ull && g_ctl(&ctl[cBail]) == 0 &&
+          __hip_atomic_load(a.status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0) {  // abandon the launch (status[2]: the host re-runs
+        if (lane == 0) {                                                                  // Phase A with the vector-chain kernel)
+          give_up();
+          __hip_atomic_store(a.status + 2, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
       }
       // The obs' diagnostics and sweep coefficients, once per block and one ob per lane, from what is in LDS anyway:
       // km of the ob's own row is kc rden with kc = G_kk/(M-1), and that row is scaled by (1 - kb_k)  (:144-149).
@@ -523,7 +535,7 @@ __global__ __launch_bounds__(kGT) void k_pipe_band(const PipeArgs a) {
         const double2 gk = SG(lane)[lane];                                     // G_kk, kb_k at the ob's own step
         const double2 rb = make_double2(l_rd, l_be);                           // rden, beta
         const double var = l_var;
-        const bool act = ((asm_mask >> lane) & 1) != 0;
+        const bool act = my_asm;
         const double innov = val_l - l_xm;                                     // :85
         a.prior_mean[f] = l_xm;                                                // :66
         a.prior_var[f] = var;                                                  // :70
@@ -556,10 +568,6 @@ __global__ __launch_bounds__(kGT) void k_pipe_band(const PipeArgs a) {
   // ======================================================================================
   if (wave >= kVW) {
     if (!leads) return;
-    // the block's ob constants are fetched now, while the wave waits for its block anyway
-    const bool pre_ob = lane < nb;
-    const double pre_err = (wave == kVW && pre_ob) ? a.ob_error[own0 + lane] : 1.0;
-    const bool pre_asm = (wave == kVW && pre_ob) ? (a.ob_assim[own0 + lane] != 0) : false;
     if (GC) {  // the three waves that only wait here fetch the block's corner of the obs-obs taper table (ensrf.py:99-115 on the obs rows)
       for (int i = (wave - kVW) * 64 + lane; i < kRowsWG * kRowsWG; i += 3 * 64) {
         const long kg = own0 + (i >> 6), rg = own0 + (i & 63);
@@ -579,60 +587,47 @@ __global__ __launch_bounds__(kGT) void k_pipe_band(const PipeArgs a) {
       // ob's lane (v_readlane), the band's later rows are downdated in registers, nothing is read from LDS
       // inside a band, and the step's record is written at its end.  Gain chain as in efa_pipeline_gram.hip:
       //   kdenom -> q0 = rsq(kdenom) -> { Newton step of q  ||  beta0 = 1/(1 + sqrt(err) q0) } -> beta
-      const bool my_asm = pre_asm;
-      const u64 asm_mask = __ballot(my_asm);
-      // cancellation guard: an assimilated pivot whose G_kk fell below 1e-3 of its value at block start; accumulated
-      // in the loop, acted upon after the block (a tripped guard abandons the launch: nothing produced meanwhile is used)
-      const double gjj0 = DEFER ? pm[2 * kRowsWG + lane] : G_s[lane * kRowsWG + lane];  // |y_j|^2 at block start
-      double thr = my_asm ? 1e-3 * gjj0 : -1.0;
-      u64 bad = 0ull;
+      // (the cancellation and centring guards of this chain are kept by the forwarder wave, which reads every G_kk anyway)
       bool ok = true;
-      // np.var re-centres (:69): var = G_kk / M - mean^2.  The rows are mean-removed perturbations (assimilation.py:47, :147):
-      // their means are rounding residue, mean^2 is below half an ulp of both var and kdenom and changes no bit of
-      // either, so the chain does not carry the means.  A block whose pivot rows are NOT centred (mean^2 above 1e-22 of
-      // var or of the error variance; the means of the 64 rows mix with weights kb <= 1 inside the block) is handed to
-      // the vector-chain kernel, which computes np.var as written.
-      {
-        const double mu0 = pm[lane];
-        const double lim = 1e-22 * fmin(pre_err, gjj0 * invM);
-        bad |= __ballot(pre_ob && !(mu0 * mu0 <= lim));
-      }
       double band[kBand];
 #pragma unroll
       for (int s = 0; s < kBand; ++s) band[s] = G_s[s * kRowsWG + lane];
       // Every value that came from LDS is pinned HERE: the compiler waits for a load where its result is first used;
       // left inside the step code such a wait would be executed every step.
 #define EFA_PIN_BAND(a) _Pragma("unroll") for (int pin_i = 0; pin_i < kBand; ++pin_i) asm volatile("" : "+v"(a[pin_i]))
-      asm volatile("" : "+v"(thr));
       EFA_PIN_BAND(band);
-      // {error, sqrt(error)} of the band's four obs: wave-uniform loads one band ahead (no v_readlane on the chain)
-      const double* ecp = a.ob_errsq + 2 * own0;
-      double ec_nx[kBand][2];
+      // {error, sqrt(error), assimilate} of the band's four obs: wave-uniform loads one band ahead (no v_readlane on the chain)
+      const double* ecp = a.ob_errsq + 4 * own0;
+      double ec_nx[kBand][3];
 #pragma unroll
       for (int s = 0; s < kBand; ++s) {
         const int o = (s < nb) ? s : 0;
-        ec_nx[s][0] = ecp[2 * o];
-        ec_nx[s][1] = ecp[2 * o + 1];
+        const double2 e01 = *reinterpret_cast<const double2*>(ecp + 4 * o);
+        ec_nx[s][0] = e01.x;
+        ec_nx[s][1] = e01.y;
+        ec_nx[s][2] = ecp[4 * o + 2];
       }
       double gprev[kBand - kEarly], gamprev[kBand - kEarly];  // rows and gammas of the previous band's late steps
       double kbprev[kBand - kEarly], tprev[kBand - kEarly];   // GC: their gains kb_j and t_j = G_kj - kb_j G_kk
-#pragma unroll
-      for (int o = 0; o < kBand - kEarly; ++o) gprev[o] = gamprev[o] = kbprev[o] = tprev[o] = 0.0;
       EFA_BLOCKSTAMP(lane == 0, 0);
       EFA_WAIT_OUT(lane == 0, 5, 5, __builtin_amdgcn_s_memrealtime());
       EFA_HO(8, 4);   // T5: the pivot starts band 0
-      EFA_PS(u64 ps_wait = 0; const u64 ps_t0 = EFA_PS_NOW();)
+      EFA_PS(u64 ps_wait = 0; const u64 ps_t0 = EFA_PS_NOW(); u64 ps_ld = 0; u64 ps_ap = 0; u64 ps_st = 0; u64 ps_en = 0; u64 ps_hd = 0;)
       for (int b = 0; b < nbands && ok; ++b) {
+        EFA_PS(const u64 ps_top = EFA_PS_NOW();)
         const int r0 = kBand * b;
         const int s1 = (nb - r0 < kBand) ? nb - r0 : kBand;  // steps of this band
-        double ec[kBand][2];
+        double ec[kBand][3];
 #pragma unroll
         for (int s = 0; s < kBand; ++s) {
           ec[s][0] = ec_nx[s][0];
           ec[s][1] = ec_nx[s][1];
+          ec[s][2] = ec_nx[s][2];
           const int o = (r0 + kBand + s < nb) ? r0 + kBand + s : 0;
-          ec_nx[s][0] = ecp[2 * o];
-          ec_nx[s][1] = ecp[2 * o + 1];
+          const double2 e01 = *reinterpret_cast<const double2*>(ecp + 4 * o);
+          ec_nx[s][0] = e01.x;
+          ec_nx[s][1] = e01.y;
+          ec_nx[s][2] = ecp[4 * o + 2];
         }
         if (DEFER && r0 == Sh::kSgE) {  // the step records move into the union from here: the parked tile must be done with
           ok = wait_gt(&ctl[cDef], 11, false);
@@ -641,28 +636,32 @@ __global__ __launch_bounds__(kGT) void k_pipe_band(const PipeArgs a) {
         if (b > 0) {  // the band's rows, current through the previous band, from the two G waves
           EFA_PS(const u64 ps_a = EFA_PS_NOW();)
           if (!EFA_EXP(2048) && (kEarly > 0 || b >= 2)) ok = wait_gt2(&ctl[cBandH], b - 1);  // kEarly == 0: band 1's rows are the initial ones
-          EFA_PS(const u64 ps_r = EFA_PS_NOW(); ps_wait += ps_r - ps_a;
-                 if (a.dbg != nullptr && lane == 0 && own0 + 64 + b < P) { a.dbg[(size_t)(own0 + 64 + b) * 8 + 1] = ps_a; a.dbg[(size_t)(own0 + 64 + b) * 8 + 2] = ps_r; })
           if (!ok) break;
 #pragma unroll
           for (int s = 0; s < kBand; ++s) band[s] = G_s[(r0 + s) * kRowsWG + lane];
+          EFA_PS(const u64 ps_r = EFA_PS_NOW(); ps_wait += ps_r - ps_a;
+                 if (a.dbg != nullptr && lane == 0 && own0 + 64 + b < P) { a.dbg[(size_t)(own0 + 64 + b) * 8 + 1] = ps_a; a.dbg[(size_t)(own0 + 64 + b) * 8 + 2] = ps_r; })
           EFA_PIN_BAND(band);
+          EFA_PS(const u64 ps_l = EFA_PS_NOW(); ps_ld += ps_l - ps_r; ps_hd += ps_a - ps_top;)
           // the G waves handed these rows over EARLY, current through the first kEarly steps of the previous band
-          // (so that this wave never waits for them); the rest of that band is applied here, in order
+          // (so that this wave never waits for them); the rest of that band is applied here, in order.
 #pragma unroll
           for (int o = 0; o < kBand - kEarly; ++o) {
 #pragma unroll
             for (int s2 = 0; s2 < kBand; ++s2) {
               const double gi = rl(gprev[o], r0 + s2);
+              const double kbi = GC ? rl(kbprev[o], r0 + s2) : 0.0;
               if (GC) {  // the taper makes the downdate two-term: G_ij -= kb_j G_ki + kb_i t_j
                 band[s2] = __builtin_fma(-gi, kbprev[o], band[s2]);
-                band[s2] = __builtin_fma(-rl(kbprev[o], r0 + s2), tprev[o], band[s2]);
+                band[s2] = __builtin_fma(-kbi, tprev[o], band[s2]);
               } else {
                 band[s2] = __builtin_fma(-gi, gamprev[o], band[s2]);  // gamprev holds the VECTOR gamma g: one product per step, not per row
               }
             }
           }
+          EFA_PS(EFA_PIN_BAND(band); ps_ap += EFA_PS_NOW() - ps_l;)
         }
+        EFA_PS(const u64 ps_s0 = EFA_PS_NOW();)
         // (L^-1)[s][t] for this band, lane t holds column t (lanes >= 8 carry zeros): right-looking,
         // linv[s'] -= L[s'][s] linv[s] once row s is final
         double linv[kBand];
@@ -672,73 +671,80 @@ __global__ __launch_bounds__(kGT) void k_pipe_band(const PipeArgs a) {
 #pragma unroll
         for (int s = 0; s < kBand; ++s) tw4[s] = GC ? tw_s[(r0 + (s < s1 ? s : 0)) * kRowsWG + lane] : 1.0;
         if (GC) EFA_PIN_BAND(tw4);
+        // One wave issues in order and every instruction -- scalar ones too -- takes an issue slot: half of what this loop
+        // issued was scalar bookkeeping (the assimilate bit and the guard's bit mask per step, the record's address, the
+        // tests for a partial band).  The assimilate flag now comes with the ob's constants, the guards live in the forwarder
+        // wave, the band's records have one base address, and a full band (every band but a block's last, at most) runs a
+        // copy of the steps without the partial-band tests.
+        double2* const recb = SG(r0) + lane;  // step r0 + s writes recb[s * kRowsWG] (a band never straddles the records' two areas)
+        auto run_steps = [&](auto full_tag) {
+          constexpr bool FULL = decltype(full_tag)::value;
 #pragma unroll
-        for (int s = 0; s < kBand; ++s) {
-          if (s < s1) {  // wave-uniform
-            const int kk = r0 + s;
-            const double g = band[s];
-            const bool act = ((asm_mask >> kk) & 1) != 0;
-            bad |= __ballot(!(g > thr)) & (1ull << kk);
-            const double Gkk = rl(g, kk);
-            double cc = gain_c(Gkk, invM, ec[s][0], ec[s][1], rM1);       // beta / ((M-1) kdenom)  (:95, :119, :135, :136)
-            cc = act ? cc : 0.0;                                          // :74: an ob that is not assimilated changes nothing
-            double kb = cc * g;                                           // the rows' gains (:136)
-            if (GC) kb = tw4[s] * kb;                                     // :115
-            // this step's rank-one downdate of G is gamma g g^T, gamma = c (2 - c G_kk) with c = kb_j / G_kj: the form
-            // the band's later rows (and L, below) use -- one v_readlane pair per row instead of two
-            const double gam = cc * __builtin_fma(-cc, Gkk, 2.0);
-            const double tj = GC ? __builtin_fma(-kb, Gkk, g) : 0.0;      // t_j = G_kj - kb_j G_kk
-            const double gg = gam * g;                                    // the step's downdate of row i is G_ki (gamma g)
+          for (int s = 0; s < kBand; ++s) {
+            if (FULL || s < s1) {  // wave-uniform
+              const int kk = r0 + s;
+              const double g = band[s];
+              const double Gkk = rl(g, kk);
+              double cc = gain_c(Gkk, invM, ec[s][0], ec[s][1], rM1);       // beta / ((M-1) kdenom)  (:95, :119, :135, :136)
+              cc = (ec[s][2] != 0.0) ? cc : 0.0;                            // :74: an ob that is not assimilated changes nothing
+              double kb = cc * g;                                           // the rows' gains (:136)
+              if (GC) kb = tw4[s] * kb;                                     // :115
+              // this step's rank-one downdate of G is gamma g g^T, gamma = c (2 - c G_kk) with c = kb_j / G_kj: the form
+              // the band's later rows (and L, below) use -- one v_readlane pair per row instead of two
+              const double gam = cc * __builtin_fma(-cc, Gkk, 2.0);
+              const double tj = GC ? __builtin_fma(-kb, Gkk, g) : 0.0;      // t_j = G_kj - kb_j G_kk
+              const double gg = gam * g;                                    // the step's downdate of row i is G_ki (gamma g)
 #pragma unroll
-            for (int s2 = s + 1; s2 < kBand; ++s2) {
-              const double gi = rl(g, r0 + s2);                           // G_k,i of row i = r0 + s2
-              if (GC) {  // kb_j = w_kj c G_kj is no longer a multiple of G_kj: the two-term form, kb_i by v_readlane
-                const double kbi = rl(kb, r0 + s2);
-                band[s2] = __builtin_fma(-gi, kb, band[s2]);
-                band[s2] = __builtin_fma(-kbi, tj, band[s2]);
-                linv[s2] = __builtin_fma(-kbi, linv[s], linv[s2]);        // L[s2][s] = kb_i
-              } else {
-                band[s2] = __builtin_fma(-gi, gg, band[s2]);
-                linv[s2] = __builtin_fma(-(cc * gi), linv[s], linv[s2]);  // L[s2][s] = kb_i = c G_k,i
+              for (int s2 = s + 1; s2 < kBand; ++s2) {
+                const double gi = rl(g, r0 + s2);                           // G_k,i of row i = r0 + s2
+                if (GC) {  // kb_j = w_kj c G_kj is no longer a multiple of G_kj: the two-term form, kb_i by v_readlane
+                  const double kbi = rl(kb, r0 + s2);
+                  band[s2] = __builtin_fma(-gi, kb, band[s2]);
+                  band[s2] = __builtin_fma(-kbi, tj, band[s2]);
+                  linv[s2] = __builtin_fma(-kbi, linv[s], linv[s2]);        // L[s2][s] = kb_i
+                } else {
+                  band[s2] = __builtin_fma(-gi, gg, band[s2]);
+                  linv[s2] = __builtin_fma(-(cc * gi), linv[s], linv[s2]);  // L[s2][s] = kb_i = c G_k,i
+                }
               }
-            }
-            SG(kk)[lane] = make_double2(g, kb);              // the step's record: {G_kj, kb_j} per row
-            if (s == kEarly - 1 && lane == 0) g_ctl_set(&ctl[cHalf], 2 * b + 1);  // the G waves may start on the next band's rows
-            EFA_PS(if (s == kEarly - 1 && a.dbg != nullptr && lane == 0 && own0 + 64 + b < P) a.dbg[(size_t)(own0 + 64 + b) * 8 + 0] = EFA_PS_NOW();)
-            if (s >= kEarly) {
-              gprev[s - kEarly] = g;
-              gamprev[s - kEarly] = gg;
-              if (GC) {
-                kbprev[s - kEarly] = kb;
-                tprev[s - kEarly] = tj;
+              recb[s * kRowsWG] = make_double2(g, kb);         // the step's record: {G_kj, kb_j} per row
+              if (s == kEarly - 1 && lane == 0) g_ctl_set(&ctl[cHalf], 2 * b + 1);  // the G waves may start on the next band's rows
+              EFA_PS(if (s == kEarly - 1 && a.dbg != nullptr && lane == 0 && own0 + 64 + b < P) a.dbg[(size_t)(own0 + 64 + b) * 8 + 0] = EFA_PS_NOW();)
+              if (s >= kEarly) {
+                gprev[s - kEarly] = g;
+                gamprev[s - kEarly] = gg;
+                if (GC) {
+                  kbprev[s - kEarly] = kb;
+                  tprev[s - kEarly] = tj;
+                }
               }
             }
           }
-        }
-        // per band: L^-1 (LinvA[b][t][s], zero where s < t or s >= 8), flags
-        if (lane < kBand) {
-          double* dst = LinvA + ((size_t)b * kBand + lane) * kBand;
+          // per band: L^-1 (LinvA[b][t][s], zero where s < t or s >= 8)
+          if (lane < kBand) {
+            double* dst = LinvA + ((size_t)b * kBand + lane) * kBand;
 #pragma unroll
-          for (int s = 0; s < kBand; ++s) dst[s] = (s < s1) ? linv[s] : 0.0;
-        }
+            for (int s = 0; s < kBand; ++s) dst[s] = (FULL || s < s1) ? linv[s] : 0.0;
+          }
+        };
+        if (s1 == kBand) run_steps(std::true_type());
+        else run_steps(std::false_type());
+        EFA_PS(EFA_PIN_BAND(band); const u64 ps_s1 = EFA_PS_NOW(); ps_st += ps_s1 - ps_s0;)
         if (lane == 0) {
           g_ctl_set(&ctl[cSReady], r0 + s1);
           g_ctl_set(&ctl[cLinv], b + 1);
         }
+        EFA_PS(ps_en += EFA_PS_NOW() - ps_s1;)
       }
+      EFA_PS(if (a.dbg != nullptr && lane == 0 && own0 + 16 < P) {
+        u64* d = a.dbg + (size_t)(own0 + 16) * 8;
+        d[0] = ps_ld; d[1] = ps_ap; d[2] = ps_st; d[3] = ps_en; d[4] = ps_hd;
+      })
       EFA_HO(8, 5);   // T0: the pivot has finished the block's last step
       EFA_PS(if (a.dbg != nullptr && lane == 0) {
         a.dbg[(size_t)own0 * 8 + 0] = EFA_PS_NOW() - ps_t0;
         a.dbg[(size_t)own0 * 8 + 1] = ps_wait;
       })
-      // (not when the launch is being abandoned anyway: then this block may have run on rows that were never parked)
-      if (ok && bad != 0ull && g_ctl(&ctl[cBail]) == 0 &&
-          __hip_atomic_load(a.status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0) {  // the downdate may have cancelled: abandon the launch (status[2]: the host re-runs
-        if (lane == 0) {        // Phase A with the vector-chain kernel)
-          give_up();
-          __hip_atomic_store(a.status + 2, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
-      }
       EFA_BLOCKSTAMP(lane == 0, 1);
       __syncthreads();  // B3
       return;
@@ -1024,10 +1030,18 @@ __global__ __launch_bounds__(kGT) void k_pipe_band(const PipeArgs a) {
               ye0[J] = yt[0];
             }
             // D[s = 4 v + lr][col = lc]: register 0 holds ye_{r0 + lr}, which is also B[k = lr][j = lc] of the update
+            {  // the ye part of the band's records, straight to the trajectory (its scalars come from the forwarder wave)
+              u64* grec = a.traj + (size_t)(own0 + r0 + ((lr < s1) ? lr : 0)) * TS;
+              if (lr < s1) {
+#pragma unroll
+                for (int J = 0; J < NJ; ++J)
+                  if (16 * J + lc < PAD) g_traj_store(grec + 16 * J + lc, ye0[J]);
+              }
+            }
 #pragma unroll
             for (int J = 0; J < NJ; ++J)
               if (16 * J + lc < PAD) ring[(size_t)((own0 + r0 + lr) % kRingG) * TSR + 16 * J + lc] = ye0[J];
-            if (lane == 0) g_ctl_set(&ctl[cYe], 4 * (b + 1));  // the forwarder and the other vector waves may read the band
+            if (lane == 0) g_ctl_set(&ctl[cYe], 4 * (b + 1));  // the other vector waves may read the band
           } else {
             if (!wait_gt(&ctl[cYe], 4 * (b + 1) - 1, false)) {
               bailed = true;

@@ -29,6 +29,9 @@ med = lambda f: float(np.median([f(b) for b in range(1, nb)]))
 print("bits %d" % bits, "kind %d obs_ms %.3f" % (ctx.get_option("phase_a_kind"), ctx.last_timing()["obs_ms"]))
 print("pivot loop %.0f cycles per block (%.0f per step), of which waiting for the G waves' rows %.0f"
       % (med(lambda b: t[64 * b, 0]), med(lambda b: t[64 * b, 0]) / 64, med(lambda b: t[64 * b, 1])))
+r = [med(lambda b, i=i: t[64 * b + 16, i]) for i in range(5)]
+print("pivot loop per block: band head (ob constants, deferred-Gram wait) %.0f | LDS row loads after the wait %.0f | previous band applied (16 v_readlane pairs + FMA) %.0f | the four steps %.0f | L^-1 store + flags %.0f  (each interval ends in an s_memtime: +100-150 cycles per band each)"
+      % (r[4], r[0], r[1], r[2], r[3]))
 for h in (0, 1):
     r = [med(lambda b, i=i: t[64 * b + h, 2 + i]) for i in range(5)]
     print("G wave %d per block: wait first half %.0f | phase 1 %.0f (its operand loads %.0f) | wait band end %.0f | phase 2 %.0f  (sum %.0f)"
