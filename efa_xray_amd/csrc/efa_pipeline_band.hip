@@ -1100,7 +1100,7 @@ __global__ __launch_bounds__(kGT) void k_pipe_band(const PipeArgs a) {
       bailed = true;
       break;
     }
-    long avail = g_ctl(&ctl[cReady]);
+    long avail = g_ctl(&ctl[cReady]);  // (read again: reusing the value the wait saw measured slower -- more has usually arrived by now)
     const long lim = (leads && k < own0) ? own0 : P;
     if (avail > lim) avail = lim;
     if (avail > k + kRingG / 2) avail = k + kRingG / 2;  // progress is reported at least every half ring (slot recycling)
@@ -1115,7 +1115,7 @@ __global__ __launch_bounds__(kGT) void k_pipe_band(const PipeArgs a) {
     };
     auto apply = [&](const double (&y)[2 * NC], const double2 s01, const double w) {
       if (EFA_EXP(4096)) return;  // timing experiment: followers do no arithmetic
-      if (__builtin_amdgcn_readfirstlane((int)(s01.x != 0.0)) != 0) {
+      if (__ballot(s01.x != 0.0) != 0ull) {  // (the same value in every lane: c = 0 marks an ob that is not assimilated)
         double dot = group_dot<PLg, NC>(x, y);              // :95
         if (GC) dot = w * dot;                              // :115
         xm = __builtin_fma(s01.y, dot, xm);                 // :119, :130
@@ -1124,13 +1124,15 @@ __global__ __launch_bounds__(kGT) void k_pipe_band(const PipeArgs a) {
         for (int c = 0; c < 2 * NC; ++c) x[c] = __builtin_fma(-kb, y[c], x[c]);  // :141
       }
     };
+    // (the prefetch is UNCONDITIONAL -- past the batch it re-reads the batch's last record: behind a conditional prefetch the
+    //  compiler cannot count the LDS reads in flight and waits for all of them, the next record's included, before every apply)
     fetch(k, ya, a01, wa);
     while (k < avail) {
-      if (k + 1 < avail) fetch(k + 1, yb2, b01, wb);
+      fetch((k + 1 < avail) ? k + 1 : avail - 1, yb2, b01, wb);
       apply(ya, a01, wa);
       ++k;
       if (k >= avail) break;
-      if (k + 1 < avail) fetch(k + 1, ya, a01, wa);
+      fetch((k + 1 < avail) ? k + 1 : avail - 1, ya, a01, wa);
       apply(yb2, b01, wb);
       ++k;
     }
