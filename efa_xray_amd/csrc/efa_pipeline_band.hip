@@ -1115,7 +1115,9 @@ __global__ __launch_bounds__(kGT) void k_pipe_band(const PipeArgs a) {
     };
     auto apply = [&](const double (&y)[2 * NC], const double2 s01, const double w) {
       if (EFA_EXP(4096)) return;  // timing experiment: followers do no arithmetic
-      if (__ballot(s01.x != 0.0) != 0ull) {  // (the same value in every lane: c = 0 marks an ob that is not assimilated)
+      // c = 0 marks an ob that is not assimilated (the same value in every lane); with Gaspari-Cohn a record whose taper is 0 on all
+      // sixteen rows of this wave changes nothing either (ensrf.py:115: kcov x 0) -- most records, at a cut-off of a few thousand km
+      if (__ballot(s01.x != 0.0 && (!GC || w != 0.0)) != 0ull) {
         double dot = group_dot<PLg, NC>(x, y);              // :95
         if (GC) dot = w * dot;                              // :115
         xm = __builtin_fma(s01.y, dot, xm);                 // :119, :130
