@@ -169,6 +169,7 @@ struct efa_ctx {
   // --- timing -----------------------------------------------------------------
   hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
   double state_ms = 0.0, obs_ms = 0.0;
+  bool obs_ms_pending = false;  // ev[0] .. ev[1] of the last obs phase not read yet
   long state_launches = 0;
   int path_taken = 0;
 };
@@ -222,6 +223,7 @@ int obs_phase(efa_ctx* c, int M, long P, double* ym_dev, double* Yp_dev, const d
   c->n_active = 0;
   c->have_transform = false;
   c->obs_ms = 0.0;
+  c->obs_ms_pending = false;
   if (P == 0) {
     c->have_traj = true;
     c->h_assim.clear();
@@ -253,25 +255,22 @@ int obs_phase(efa_ctx* c, int M, long P, double* ym_dev, double* Yp_dev, const d
   const long R = P + extra;
   const size_t dP = (size_t)P * sizeof(double);
 
-  // per-ob inputs: [value | error | lat | lon | halfwidth | assim bytes] in one allocation, one H2D from pinned memory
+  // per-ob inputs: [value | error | assim bytes | {error, sqrt(error), assimilate (1.0 / 0.0), 0} x P | lat | lon | halfwidth] in one
+  // allocation, ONE H2D from pinned memory (the last three slots only with localisation); the four-double records are the band
+  // leader's per-ob constants, fetched with wave-uniform loads
   {
     const bool gc = loc_mode == EFA_LOC_GC;
     const size_t slot = ((size_t)P * sizeof(double) + 255) & ~(size_t)255;
-    const size_t total = 10 * slot;  // ... | {error, sqrt(error), assimilate (1.0 / 0.0), 0}: the band leader's per-ob constants, fetched with wave-uniform loads
+    const size_t total = 10 * slot;
     EFA_TRY(c->ob_pack.reserve(total));
     EFA_TRY(c->pin_in.reserve(total));
     char* hb = static_cast<char*>(c->pin_in.p);
     char* db = static_cast<char*>(c->ob_pack.p);
     std::memcpy(hb, ob_value, dP);
     std::memcpy(hb + slot, ob_error, dP);
-    if (gc) {
-      std::memcpy(hb + 2 * slot, ob_lat, dP);
-      std::memcpy(hb + 3 * slot, ob_lon, dP);
-      std::memcpy(hb + 4 * slot, ob_hw, dP);
-    }
-    std::memcpy(hb + 5 * slot, ob_assim, (size_t)P);
+    std::memcpy(hb + 2 * slot, ob_assim, (size_t)P);
     {
-      double* ec = reinterpret_cast<double*>(hb + 6 * slot);
+      double* ec = reinterpret_cast<double*>(hb + 3 * slot);
       for (long k = 0; k < P; ++k) {
         ec[4 * k] = ob_error[k];
         ec[4 * k + 1] = std::sqrt(ob_error[k]);
@@ -279,19 +278,19 @@ int obs_phase(efa_ctx* c, int M, long P, double* ym_dev, double* Yp_dev, const d
         ec[4 * k + 3] = 0.0;
       }
     }
-    c->ob_errsq.carve(db + 6 * slot, 4 * slot);
+    if (gc) {
+      std::memcpy(hb + 7 * slot, ob_lat, dP);
+      std::memcpy(hb + 8 * slot, ob_lon, dP);
+      std::memcpy(hb + 9 * slot, ob_hw, dP);
+    }
     c->ob_val.carve(db, slot);
     c->ob_err.carve(db + slot, slot);
-    c->ob_lat.carve(db + 2 * slot, slot);
-    c->ob_lon.carve(db + 3 * slot, slot);
-    c->ob_hw.carve(db + 4 * slot, slot);
-    c->ob_asm.carve(db + 5 * slot, slot);
-    if (gc) {
-      EFA_HIP(hipMemcpyAsync(db, hb, total, hipMemcpyHostToDevice, c->stream));
-    } else {
-      EFA_HIP(hipMemcpyAsync(db, hb, 2 * slot, hipMemcpyHostToDevice, c->stream));
-      EFA_HIP(hipMemcpyAsync(db + 5 * slot, hb + 5 * slot, 5 * slot, hipMemcpyHostToDevice, c->stream));
-    }
+    c->ob_asm.carve(db + 2 * slot, slot);
+    c->ob_errsq.carve(db + 3 * slot, 4 * slot);
+    c->ob_lat.carve(db + 7 * slot, slot);
+    c->ob_lon.carve(db + 8 * slot, slot);
+    c->ob_hw.carve(db + 9 * slot, slot);
+    EFA_HIP(hipMemcpyAsync(db, hb, gc ? total : 7 * slot, hipMemcpyHostToDevice, c->stream));
   }
   EFA_TRY(c->Ye_rec.reserve((size_t)P * M * sizeof(double)));
   EFA_TRY(c->coef.reserve((size_t)P * kCoefStride * sizeof(double)));
@@ -314,9 +313,8 @@ int obs_phase(efa_ctx* c, int M, long P, double* ym_dev, double* Yp_dev, const d
   if (c->timing) EFA_HIP(hipEventRecord(c->ev[0], s));
   double* Yw = c->Yw.as<double>();
   double* ymw = c->ymw.as<double>();
-  EFA_HIP(hipMemcpyAsync(Yw, Yp_dev, (size_t)P * M * sizeof(double), hipMemcpyDeviceToDevice, s));
-  EFA_HIP(hipMemcpyAsync(ymw, ym_dev, dP, hipMemcpyDeviceToDevice, s));
-  if (carry_T) EFA_HIP(launch_set_identity(M, Yw + (size_t)P * M, ymw + P, s));
+  // (the copies of the caller's block into the working rows, the identity rows, the sentinel fill of the records and the
+  //  clearing of the status words are ONE launch: launch_phase_a_prep below, once the record stride is known)
 
   // ---- Phase A in WINDOWS of observations -----------------------------------------------------------------
   // A persistent launch keeps 64 obs rows per workgroup and needs its whole grid resident: at most kPipeMaxWGs * 64
@@ -336,11 +334,14 @@ int obs_phase(efa_ctx* c, int M, long P, double* ym_dev, double* Yp_dev, const d
   const long TS = TS_std > TS_band ? TS_std : TS_band;
   const long B = effective_batch(c, M);
   bool traj_kind_band = false, any_pipeline = false, any_batch = false;
+  bool diag_on_host = false;  // the diagnostics are already in pin_out (copied with the status words of the one launch that did it all)
   if (pipe_ok) {
     EFA_TRY(c->traj.reserve((size_t)P * TS * sizeof(unsigned long long)));
     EFA_TRY(c->status.reserve(3 * sizeof(int)));
-    EFA_HIP(launch_fill_u64(c->traj.as<unsigned long long>(), (size_t)P * TS, kTrajSentinel, s));
   }
+  EFA_HIP(launch_phase_a_prep(P, M, Yp_dev, ym_dev, Yw, ymw, carry_T ? 1 : 0, pipe_ok ? c->traj.as<unsigned long long>() : nullptr,
+                              pipe_ok ? (size_t)P * TS : 0, kTrajSentinel, pipe_ok ? c->status.as<int>() : nullptr, s));
+  bool status_clear = pipe_ok;  // (cleared by the prep launch: the first window's launch needs no memset of its own)
   // rows [lo, hi) of the obs block take obs [b0, b0 + nb) from (Ye, ye_stride): the per-batch sweep
   auto sweep_rows = [&](long b0, int nb, const double* Ye, long ye_stride, long skip_lo, long skip_hi, long nrows) -> int {
     SweepArgs a{};
@@ -427,7 +428,8 @@ int obs_phase(efa_ctx* c, int M, long P, double* ym_dev, double* Yp_dev, const d
         return EFA_OK;
       };
       EFA_TRY(stage_in());
-      EFA_HIP(hipMemsetAsync(c->status.p, 0, 3 * sizeof(int), s));
+      if (!status_clear) EFA_HIP(hipMemsetAsync(c->status.p, 0, 3 * sizeof(int), s));
+      status_clear = false;
       PipeArgs pa{};
       pa.Yp = Wy;
       pa.ym = Wm;
@@ -486,14 +488,19 @@ int obs_phase(efa_ctx* c, int M, long P, double* ym_dev, double* Yp_dev, const d
           continue;
         }
         EFA_HIP(le);
-        int st[3] = {0, 0, 0};
-        EFA_HIP(hipMemcpyAsync(st, c->status.p, sizeof(st), hipMemcpyDeviceToHost, s));
+        // ONE host round trip per launch: the status words and -- when this launch is the whole Phase A -- the diagnostics
+        // it wrote come back together, into pinned memory (a second copy + synchronise after the status was known left the
+        // device idle for ~40 us before Phase B; a pageable destination made the status copy itself a staged one)
+        int* st = reinterpret_cast<int*>(static_cast<char*>(c->pin_out.p) + 5 * oslot - 64);
+        EFA_HIP(hipMemcpyAsync(st, c->status.p, 3 * sizeof(int), hipMemcpyDeviceToHost, s));
+        if (direct) EFA_HIP(hipMemcpyAsync(c->pin_out.p, c->out_pack.p, 4 * oslot + (size_t)P, hipMemcpyDeviceToHost, s));
         EFA_HIP(hipStreamSynchronize(s));
         if (st[0] == 0 && st[1] == 0) {
           done = true;
           any_pipeline = true;
           traj_kind_band = (kind == 4);
           c->phase_a_kind = kind;
+          diag_on_host = direct;
         } else {
           if (direct) {
             EFA_HIP(hipMemcpyAsync(Yw, Yp_dev, (size_t)P * M * sizeof(double), hipMemcpyDeviceToDevice, s));
@@ -578,8 +585,10 @@ int obs_phase(efa_ctx* c, int M, long P, double* ym_dev, double* Yp_dev, const d
   if (c->timing) EFA_HIP(hipEventRecord(c->ev[1], s));
 
   // diagnostics back to the caller (ensrf.py:66,70,75,146-149)
-  EFA_HIP(hipMemcpyAsync(c->pin_out.p, c->out_pack.p, 4 * oslot + (size_t)P, hipMemcpyDeviceToHost, s));
-  EFA_HIP(hipStreamSynchronize(s));
+  if (!diag_on_host) {
+    EFA_HIP(hipMemcpyAsync(c->pin_out.p, c->out_pack.p, 4 * oslot + (size_t)P, hipMemcpyDeviceToHost, s));
+    EFA_HIP(hipStreamSynchronize(s));
+  }
   {
     const char* hb = static_cast<const char*>(c->pin_out.p);
     if (prior_mean) std::memcpy(prior_mean, hb, dP);
@@ -595,11 +604,7 @@ int obs_phase(efa_ctx* c, int M, long P, double* ym_dev, double* Yp_dev, const d
       }
     }
   }
-  if (c->timing) {
-    float ms = 0.f;
-    EFA_HIP(hipEventElapsedTime(&ms, c->ev[0], c->ev[1]));
-    c->obs_ms = ms;
-  }
+  if (c->timing) c->obs_ms_pending = true;  // read in efa_last_timing: the copies back to the caller's block may still be in flight
   c->have_transform = carry_T;
   c->have_traj = true;
   return EFA_OK;
@@ -1251,6 +1256,11 @@ int efa_cov_contract_f32_dev(efa_ctx* c, long N, int M, long P, const float* Xbp
 
 int efa_last_timing(efa_ctx* c, double* state_ms, double* obs_ms, long* state_launches, int* path_taken) {
   if (!c) return fail(EFA_ERR_INVALID, "null context");
+  if (c->obs_ms_pending) {
+    float ms = 0.f;
+    if (hipEventSynchronize(c->ev[1]) == hipSuccess && hipEventElapsedTime(&ms, c->ev[0], c->ev[1]) == hipSuccess) c->obs_ms = ms;
+    c->obs_ms_pending = false;
+  }
   if (state_ms) *state_ms = c->state_ms;
   if (obs_ms) *obs_ms = c->obs_ms;
   if (state_launches) *state_launches = c->state_launches;

@@ -186,6 +186,41 @@ hipError_t launch_occupy(int blocks, size_t lds_bytes, double ms, hipStream_t s)
   return hipGetLastError();
 }
 
+// Everything one Phase-A call needs before its first launch, in ONE launch (five small operations cost ~10 us of launch
+// latency each -- a fifth of configs[1]'s whole cycle): the caller's obs block into the working rows, the identity rows
+// that come out as [T|w], the trajectory records filled with their sentinel, the status words cleared.
+__global__ void k_phase_a_prep(long P, int M, const double* __restrict__ Yp, const double* __restrict__ ym, double* __restrict__ Yw,
+                               double* __restrict__ ymw, int carry_T, unsigned long long* __restrict__ traj, size_t traj_words,
+                               unsigned long long sentinel, int* __restrict__ status) {
+  const size_t tid = (size_t)blockIdx.x * blockDim.x + threadIdx.x, nth = (size_t)gridDim.x * blockDim.x;
+  const size_t n = (size_t)P * M;
+  if ((n & 1) == 0 && ((reinterpret_cast<uintptr_t>(Yp) | reinterpret_cast<uintptr_t>(Yw)) & 15u) == 0) {
+    const double2* src = reinterpret_cast<const double2*>(Yp);
+    double2* dst = reinterpret_cast<double2*>(Yw);
+    for (size_t i = tid; i < n / 2; i += nth) dst[i] = src[i];
+  } else {
+    for (size_t i = tid; i < n; i += nth) Yw[i] = Yp[i];
+  }
+  for (size_t i = tid; i < (size_t)P; i += nth) ymw[i] = ym[i];
+  if (carry_T) {
+    double* T = Yw + n;
+    for (size_t i = tid; i < (size_t)M * M; i += nth) T[i] = (i / M == i % M) ? 1.0 : 0.0;
+    for (size_t i = tid; i < (size_t)M; i += nth) ymw[P + i] = 0.0;
+  }
+  if (traj != nullptr)
+    for (size_t i = tid; i < traj_words; i += nth) traj[i] = sentinel;
+  if (status != nullptr && tid < 3) status[tid] = 0;
+}
+
+hipError_t launch_phase_a_prep(long P, int M, const double* Yp, const double* ym, double* Yw, double* ymw, int carry_T,
+                               unsigned long long* traj, size_t traj_words, unsigned long long sentinel, int* status, hipStream_t s) {
+  size_t work = (size_t)P * M / 2 + 1;
+  if (traj && traj_words > work) work = traj_words;
+  hipLaunchKernelGGL(k_phase_a_prep, dim3(grid_for(work, 256 * 4)), dim3(256), 0, s, P, M, Yp, ym, Yw, ymw, carry_T, traj, traj_words,
+                     sentinel, status);
+  return hipGetLastError();
+}
+
 hipError_t launch_set_identity(int M, double* T, double* w, hipStream_t s) {
   hipLaunchKernelGGL(k_set_identity, dim3(16), dim3(256), 0, s, M, T, w);
   return hipGetLastError();
