@@ -150,12 +150,6 @@ __device__ __forceinline__ double gain_c(double Gkk, double invM, double errk, d
   const double eu = __builtin_fma(-u, c0, 1.0);
   return __builtin_fma(c0, __builtin_fma(eu, eu, eu), c0) * rM1;
 }
-template <int Q>
-__device__ __forceinline__ double quad_bcast(double v) {  // lane Q of every quad, to the quad (DPP quad_perm [Q,Q,Q,Q])
-  const int lo = __builtin_amdgcn_mov_dpp(__double2loint(v), Q * 0x55, 0xF, 0xF, true);
-  const int hi = __builtin_amdgcn_mov_dpp(__double2hiint(v), Q * 0x55, 0xF, 0xF, true);
-  return __hiloint2double(hi, lo);
-}
 __device__ __forceinline__ double rl(double v, int lane) {  // value held by `lane` (wave-uniform index)
   const int lo = __builtin_amdgcn_readlane(__double2loint(v), lane);
   const int hi = __builtin_amdgcn_readlane(__double2hiint(v), lane);
@@ -165,9 +159,6 @@ __device__ __forceinline__ double rl(double v, int lane) {  // value held by `la
 
 #ifndef EFA_DEFER_GRAM
 #define EFA_DEFER_GRAM 1
-#endif
-#ifndef EFA_FOLLOW_MFMA
-#define EFA_FOLLOW_MFMA 1  // unlocalised cycles: the followers take a band of four records at once on the matrix cores
 #endif
 template <int NC, bool GC = false>
 struct BandShape {
@@ -206,8 +197,6 @@ __global__ __launch_bounds__(kGT) void k_pipe_band(const PipeArgs a) {
   double* Yt = U;
   double2* s_gk = reinterpret_cast<double2*>(U);  // [step][row] = {G_kj, kb_j}
   constexpr bool DEFER = Sh::kDefer;
-  constexpr bool FM = !GC && (EFA_FOLLOW_MFMA != 0);  // followers on the matrix cores (band by band)
-  static_assert(!FM || (kBand == 4 && TS - PAD == 8 && kRingG % kBand == 0), "matrix-core followers: four records per band, eight scalar words per record");
   // record of step st (per-lane or uniform st)
   auto SG = [&](int st) -> double2* { return (DEFER && st < Sh::kSgE) ? sgk_e + (size_t)st * kRowsWG : s_gk + (size_t)st * kRowsWG; };
 
@@ -368,9 +357,6 @@ __global__ __launch_bounds__(kGT) void k_pipe_band(const PipeArgs a) {
   // wave 7: loader (follower mode) / forwarder (leader mode)
   // ======================================================================================
   if (wave == 7) {
-    // (ahead of the vector wave on its SIMD: with matrix-core followers that wave issues bursts of fp64 MFMA steps, and this
-    //  wave is what brings the next records in)
-    __builtin_amdgcn_s_setprio(2);
     // Three phases, each its own loop: follow the records before the block, forward the block, follow the
     // rest (as ONE loop the compiler waits vmcnt(0) per forwarded record: see efa_pipeline.hip).
     bool failed = false;
@@ -423,33 +409,13 @@ __global__ __launch_bounds__(kGT) void k_pipe_band(const PipeArgs a) {
 #pragma unroll
         for (int d = 0; d < kPollG; ++d) {
           if (d < cnt) {
-            if constexpr (FM) {
-              // matrix-core followers: the ring holds BANDS.  A band's ye part is stored as [step pair u][record][member-in-step kk]
-              // [step parity], member 4 t + kk of step t = 2 u + parity: a follower lane's two operands of a step pair are then
-              // 16 contiguous bytes, and the 16 (record, kk) combinations of one read 256 contiguous bytes -- for the dots
-              // (lane <-> record ri, member rk) and for the update (lane <-> record rk, member ri) alike: no bank conflicts, half
-              // the LDS instructions.  The scalars of the four records follow (eight words each).
-              const long kb = next + d;
-              double* bandp = ring + (size_t)((kb >> 2) % (kRingG / kBand)) * (kBand * TS);
-              const int rec = (int)(kb & 3);
+            double* slot = ring + (size_t)((next + d) % kRingG) * TSR;
 #pragma unroll
-              for (int e = 0; e < EPL; ++e) {
-                const int idx = lane + 64 * e;
-                if (idx < TS) {
-                  // (kk ^ rec: the four records of one kk -- what the dots' read takes in four neighbouring lanes -- land in four different bank groups)
-                  const int pos = (idx < PAD) ? ((idx >> 3) * 32 + rec * 8 + (((idx & 3) ^ rec)) * 2 + ((idx >> 2) & 1)) : (kBand * PAD + rec * 8 + (idx - PAD));
-                  bandp[pos] = __longlong_as_double((long long)v[d][e]);
-                }
-              }
-            } else {
-              double* slot = ring + (size_t)((next + d) % kRingG) * TSR;
-#pragma unroll
-              for (int e = 0; e < EPL; ++e) {
-                const int idx = lane + 64 * e;
-                if (idx < TS) slot[idx] = __longlong_as_double((long long)v[d][e]);
-              }
-              if (GC) slot[TS + lane] = twv[d];
+            for (int e = 0; e < EPL; ++e) {
+              const int idx = lane + 64 * e;
+              if (idx < TS) slot[idx] = __longlong_as_double((long long)v[d][e]);
             }
+            if (GC) slot[TS + lane] = twv[d];
           }
         }
         next += cnt;
@@ -544,48 +510,14 @@ __global__ __launch_bounds__(kGT) void k_pipe_band(const PipeArgs a) {
         // the records' scalars, from the band's own lanes.  The followers read two: c = beta / ((M-1) kdenom), 0 for an ob that
         // is not assimilated, and m = innov / ((M-1) kdenom): kb_j = w c (y_j . ye), xm_j += w m (y_j . ye)
         // (:95, :115, :119, :130, :136 folded once per ob); then innov and the assimilate flag
-        const double cf = my_asm ? (l_be * l_rd) * rM1 : 0.0;
-        const double mf = (FM && !my_asm) ? 0.0 : (l_rd * rM1) * l_innov;  // (matrix-core followers have no branch on c: m is 0 with it)
-        double gq[3] = {0.0, 0.0, 0.0};  // FM: g[t][k] = ye_t . ye_k (t = 0, 1, 2 < k) of this lane's ob k within its band
-        if constexpr (FM) {
-          // The followers apply a band's four records AT ONCE on the matrix cores (see the vector waves): for that they need the
-          // couplings ye_t . ye_k of the band's records.  They follow from the step records alone: ye_k = y_k(t) - sum_{s=t}^{k-1}
-          // kb_k(s) ye_s, so g[t][k] = G_tk(t) - sum_{s=t}^{k-1} kb_k(s) g[t][s]  with G_tk(t), kb_k(t) = step t's record at row
-          // k -- this lane's own gk4[t] when the lane is ob k -- and g[t][s] (s < k) from the lanes before it in the band.
-          const int r0 = kBand * b, li = lane & 3;
-          const double u00 = rl(gk4[0].x, r0);                                  // g[0][0] = |ye_0|^2
-          double G0 = gk4[0].x;
-          G0 = (li > 0) ? __builtin_fma(-gk4[0].y, u00, G0) : G0;               // li = 1 final
-          const double u01 = rl(G0, r0 + 1);
-          G0 = (li > 1) ? __builtin_fma(-gk4[1].y, u01, G0) : G0;               // li = 2 final
-          const double u02 = rl(G0, r0 + 2);
-          G0 = (li > 2) ? __builtin_fma(-gk4[2].y, u02, G0) : G0;               // li = 3 final
-          const double u11 = rl(gk4[1].x, r0 + 1);                              // g[1][1]
-          double G1 = gk4[1].x;
-          G1 = (li > 1) ? __builtin_fma(-gk4[1].y, u11, G1) : G1;               // li = 2 final
-          const double u12 = rl(G1, r0 + 2);
-          G1 = (li > 2) ? __builtin_fma(-gk4[2].y, u12, G1) : G1;               // li = 3 final
-          const double u22 = rl(gk4[2].x, r0 + 2);                              // g[2][2]
-          double G2 = gk4[2].x;
-          G2 = (li > 2) ? __builtin_fma(-gk4[2].y, u22, G2) : G2;               // li = 3 final
-          gq[0] = G0;
-          gq[1] = G1;
-          gq[2] = G2;
-        }
         if (mine && f_ob) {
+          const double cf = my_asm ? (l_be * l_rd) * rM1 : 0.0, mf = (l_rd * rM1) * l_innov;
           g_traj_store(rec_l + 0, cf);
           g_traj_store(rec_l + 1, mf);
           g_traj_store(rec_l + 2, l_innov);
-          if constexpr (FM) {
+          const double actv = my_asm ? 1.0 : 0.0;
 #pragma unroll
-            for (int sj = 0; sj < 3; ++sj) g_traj_store(rec_l + 3 + sj, gq[sj]);  // ye_t . ye_k, t = 0, 1, 2 (those with t < k are read)
-            g_traj_store(rec_l + 6, 0.0);
-            g_traj_store(rec_l + 7, 0.0);
-          } else {
-            const double actv = my_asm ? 1.0 : 0.0;
-#pragma unroll
-            for (int sj = 3; sj < TS - PAD; ++sj) g_traj_store(rec_l + sj, actv);  // (the followers wait for every word of a record)
-          }
+          for (int sj = 3; sj < TS - PAD; ++sj) g_traj_store(rec_l + sj, actv);  // (the followers wait for every word of a record)
         }
       }
       // (not when the launch is being abandoned anyway: then this block may have run on rows that were never parked)
@@ -715,21 +647,15 @@ __global__ __launch_bounds__(kGT) void k_pipe_band(const PipeArgs a) {
           // (so that this wave never waits for them); the rest of that band is applied here, in order.
 #pragma unroll
           for (int o = 0; o < kBand - kEarly; ++o) {
-            // the four scalars of a step first, then the four updates: a v_readlane result needs two wait states before a
-            // vector instruction may read it, and back to back (readlane pair, FMA, readlane pair, FMA ...) every FMA paid them
-            double gi[kBand], kbi[kBand];
 #pragma unroll
             for (int s2 = 0; s2 < kBand; ++s2) {
-              gi[s2] = rl(gprev[o], r0 + s2);
-              kbi[s2] = GC ? rl(kbprev[o], r0 + s2) : 0.0;
-            }
-#pragma unroll
-            for (int s2 = 0; s2 < kBand; ++s2) {
+              const double gi = rl(gprev[o], r0 + s2);
+              const double kbi = GC ? rl(kbprev[o], r0 + s2) : 0.0;
               if (GC) {  // the taper makes the downdate two-term: G_ij -= kb_j G_ki + kb_i t_j
-                band[s2] = __builtin_fma(-gi[s2], kbprev[o], band[s2]);
-                band[s2] = __builtin_fma(-kbi[s2], tprev[o], band[s2]);
+                band[s2] = __builtin_fma(-gi, kbprev[o], band[s2]);
+                band[s2] = __builtin_fma(-kbi, tprev[o], band[s2]);
               } else {
-                band[s2] = __builtin_fma(-gi[s2], gamprev[o], band[s2]);  // gamprev holds the VECTOR gamma g: one product per step, not per row
+                band[s2] = __builtin_fma(-gi, gamprev[o], band[s2]);  // gamprev holds the VECTOR gamma g: one product per step, not per row
               }
             }
           }
@@ -768,21 +694,17 @@ __global__ __launch_bounds__(kGT) void k_pipe_band(const PipeArgs a) {
               const double gam = cc * __builtin_fma(-cc, Gkk, 2.0);
               const double tj = GC ? __builtin_fma(-kb, Gkk, g) : 0.0;      // t_j = G_kj - kb_j G_kk
               const double gg = gam * g;                                    // the step's downdate of row i is G_ki (gamma g)
-              double gi[kBand], kbi[kBand];                                  // (all the scalars first: see the note on wait states above)
 #pragma unroll
               for (int s2 = s + 1; s2 < kBand; ++s2) {
-                gi[s2] = rl(g, r0 + s2);                                    // G_k,i of row i = r0 + s2
-                kbi[s2] = GC ? rl(kb, r0 + s2) : 0.0;                       // GC: kb_j = w_kj c G_kj is no longer a multiple of G_kj
-              }
-#pragma unroll
-              for (int s2 = s + 1; s2 < kBand; ++s2) {
-                if (GC) {  // the two-term form, kb_i by v_readlane
-                  band[s2] = __builtin_fma(-gi[s2], kb, band[s2]);
-                  band[s2] = __builtin_fma(-kbi[s2], tj, band[s2]);
-                  linv[s2] = __builtin_fma(-kbi[s2], linv[s], linv[s2]);    // L[s2][s] = kb_i
+                const double gi = rl(g, r0 + s2);                           // G_k,i of row i = r0 + s2
+                if (GC) {  // kb_j = w_kj c G_kj is no longer a multiple of G_kj: the two-term form, kb_i by v_readlane
+                  const double kbi = rl(kb, r0 + s2);
+                  band[s2] = __builtin_fma(-gi, kb, band[s2]);
+                  band[s2] = __builtin_fma(-kbi, tj, band[s2]);
+                  linv[s2] = __builtin_fma(-kbi, linv[s], linv[s2]);        // L[s2][s] = kb_i
                 } else {
-                  band[s2] = __builtin_fma(-gi[s2], gg, band[s2]);
-                  linv[s2] = __builtin_fma(-(cc * gi[s2]), linv[s], linv[s2]);  // L[s2][s] = kb_i = c G_k,i
+                  band[s2] = __builtin_fma(-gi, gg, band[s2]);
+                  linv[s2] = __builtin_fma(-(cc * gi), linv[s], linv[s2]);  // L[s2][s] = kb_i = c G_k,i
                 }
               }
               recb[s * kRowsWG] = make_double2(g, kb);         // the step's record: {G_kj, kb_j} per row
@@ -1020,25 +942,15 @@ __global__ __launch_bounds__(kGT) void k_pipe_band(const PipeArgs a) {
   // ======================================================================================
   const int j = lane & (PLg - 1);
   const int grp = lane / PLg;
-  // FM (matrix-core followers, unlocalised): the rows are held as X^T tiles of v_mfma_f64_4x4x4_4b -- register t of lane l is
-  // member 4 t + (l >> 4) of the wave's row (l & 15): as the B operand of the dots (k = member, j = row) and as the
-  // accumulator of the update (i = member, j = row) alike, so a band is 26 + 26 matrix-core steps and no layout change.
-  // Otherwise: quad per row (lane j of a quad holds members 8 c + 2 j, + 1).
-  const int kk = lane >> 4;                                    // FM: this lane's member within a step of four
-  const int i_loc = FM ? wave + kVW * (lane & 15) : wave + kVW * grp;  // consecutive obs in different waves
+  const int i_loc = wave + kVW * grp;  // consecutive obs in different waves
   const long row = own0 + i_loc;
   const bool live = row < R;
   const bool vec = (M % 2 == 0);
   double x[2 * NC];
   double xm = 0.0;
   if (live) {
-    if constexpr (FM) {
-#pragma unroll
-      for (int t = 0; t < 2 * NC; ++t) x[t] = (4 * t + kk < M) ? a.Yp[(size_t)row * M + 4 * t + kk] : 0.0;
-    } else {
-      if (vec) load_row<PLg, NC, true>(a.Yp + (size_t)row * M, M, j, x);
-      else load_row<PLg, NC, false>(a.Yp + (size_t)row * M, M, j, x);
-    }
+    if (vec) load_row<PLg, NC, true>(a.Yp + (size_t)row * M, M, j, x);
+    else load_row<PLg, NC, false>(a.Yp + (size_t)row * M, M, j, x);
     xm = a.ym[row];
   } else {
 #pragma unroll
@@ -1047,7 +959,6 @@ __global__ __launch_bounds__(kGT) void k_pipe_band(const PipeArgs a) {
   int barriers_left = leads ? 3 : 0;
   bool bailed = false;
   long k = 0;
-  EFA_PS(u64 fm_cyc = 0; u64 fm_n = 0; u64 fm_wait = 0;)
   while (k < P && !bailed) {
     if (leads && k == own0) {
       // ---------------- this workgroup's block ----------------
@@ -1055,34 +966,15 @@ __global__ __launch_bounds__(kGT) void k_pipe_band(const PipeArgs a) {
       if (a.dbg != nullptr && lane == 0) a.dbg[(size_t)(own0 + wave) * 8 + 4] = __builtin_amdgcn_s_memtime();  // per vector wave
       EFA_WAIT_OUT(wave == 0 && lane == 0, 4, 7, __builtin_amdgcn_s_memrealtime());
 #endif
-      if constexpr (FM) {
-        double rs = 0.0, rn = 0.0;
 #pragma unroll
-        for (int t = 0; t < 2 * NC; ++t) {
-          Yt[(size_t)i_loc * SP + 4 * t + kk] = x[t];
-          rs += x[t];
-          rn = __builtin_fma(x[t], x[t], rn);
-        }
-        rs += __shfl_xor(rs, 16, 64);
-        rs += __shfl_xor(rs, 32, 64);
-        rn += __shfl_xor(rn, 16, 64);
-        rn += __shfl_xor(rn, 32, 64);
-        if (kk == 0) {
-          pm[i_loc] = rs * invM;
-          pm[kRowsWG + i_loc] = xm;
-          if (DEFER) pm[2 * kRowsWG + i_loc] = rn;  // G_jj for the guard (its tile comes later)
-        }
-      } else {
-#pragma unroll
-        for (int c = 0; c < NC; ++c)
-          *reinterpret_cast<double2*>(Yt + (size_t)i_loc * SP + 2 * PLg * c + 2 * j) = make_double2(x[2 * c], x[2 * c + 1]);
-        const double rmean = group_rowsum<PLg, NC>(x) * invM;
-        const double rnorm = DEFER ? group_dot<PLg, NC>(x, x) : 0.0;  // G_jj for the pivot's guard (its tile comes later)
-        if (j == 0) {
-          pm[i_loc] = rmean;
-          pm[kRowsWG + i_loc] = xm;
-          if (DEFER) pm[2 * kRowsWG + i_loc] = rnorm;
-        }
+      for (int c = 0; c < NC; ++c)
+        *reinterpret_cast<double2*>(Yt + (size_t)i_loc * SP + 2 * PLg * c + 2 * j) = make_double2(x[2 * c], x[2 * c + 1]);
+      const double rmean = group_rowsum<PLg, NC>(x) * invM;
+      const double rnorm = DEFER ? group_dot<PLg, NC>(x, x) : 0.0;  // G_jj for the pivot's guard (its tile comes later)
+      if (j == 0) {
+        pm[i_loc] = rmean;
+        pm[kRowsWG + i_loc] = xm;
+        if (DEFER) pm[2 * kRowsWG + i_loc] = rnorm;
       }
       __syncthreads();  // B1: tile and parked means complete
       EFA_BLOCKSTAMP(wave == 0 && lane == 0, 5);
@@ -1189,16 +1081,11 @@ __global__ __launch_bounds__(kGT) void k_pipe_band(const PipeArgs a) {
         bailed = true;
         break;
       }
-      if constexpr (FM) {
 #pragma unroll
-        for (int t = 0; t < 2 * NC; ++t) x[t] = Yt[(size_t)i_loc * SP + 4 * t + kk];
-      } else {
-#pragma unroll
-        for (int c = 0; c < NC; ++c) {
-          const double2 v = *reinterpret_cast<const double2*>(Yt + (size_t)i_loc * SP + 2 * PLg * c + 2 * j);
-          x[2 * c] = v.x;
-          x[2 * c + 1] = v.y;
-        }
+      for (int c = 0; c < NC; ++c) {
+        const double2 v = *reinterpret_cast<const double2*>(Yt + (size_t)i_loc * SP + 2 * PLg * c + 2 * j);
+        x[2 * c] = v.x;
+        x[2 * c + 1] = v.y;
       }
       xm = pm[kRowsWG + i_loc];  // the pivot wave carried the obs-space means through the block (:130)
       k = own1;
@@ -1209,99 +1096,12 @@ __global__ __launch_bounds__(kGT) void k_pipe_band(const PipeArgs a) {
     // without further polls, the LDS reads of record k+1 issued before the arithmetic of record k (two register
     // sets, the loop is unrolled by two), and the progress word is written once per batch: a follower is bound by
     // what one wave can issue, so every instruction per record counts.
-    const long lim = (leads && k < own0) ? own0 : P;
-    if constexpr (FM) {
-      // ---------------- matrix-core followers: whole bands of four records ----------------
-      // (bands start at multiples of four: blocks are 64 obs; only the very last band of the call can be shorter)
-      const long need = (k + kBand <= lim) ? k + kBand : lim;
-      EFA_PS(const u64 fw0 = EFA_PS_NOW();)
-      if (!wait_gt(&ctl[cReady], (int)need - 1, true)) {
-        bailed = true;
-        break;
-      }
-      EFA_PS(fm_wait += EFA_PS_NOW() - fw0;)
-      long avail = g_ctl(&ctl[cReady]);
-      if (avail > lim) avail = lim;
-      if (avail > k + kRingG / 2) avail = k + kRingG / 2;  // progress is reported at least every half ring (slot recycling)
-      const int ri = lane & 3, rk = lane >> 4;
-      while (k < avail && (avail - k >= kBand || avail == lim)) {
-        const int nrec = (int)((avail - k < kBand) ? (avail - k) : kBand);
-        const double* rb = ring + (size_t)((k >> 2) % (kRingG / kBand)) * (kBand * TS);  // the band (layout: see the loader wave)
-        const double2* pd = reinterpret_cast<const double2*>(rb + ri * 8 + (rk ^ ri) * 2);  // dots: A[i = record ri][k = member 4 t + rk], steps 2 u, 2 u + 1
-        const double2* pu = reinterpret_cast<const double2*>(rb + rk * 8 + (ri ^ rk) * 2);  // update: A[i = member 4 t + ri][k = record rk]
-        auto band = [&](auto full_tag) {
-          constexpr bool FULL = decltype(full_tag)::value;
-          if (EFA_EXP(4096)) return;  // timing experiment: followers do no arithmetic
-          // LDS first, in the order of use, every read unconditional (so that the compiler can count what is in flight): this lane's
-          // record scalars, the dots' operands, the update's operands -- 5 + 13 + 13 reads; the arithmetic below then waits for
-          // each group only where it needs it, and the small recurrence for U runs while the operands are still on their way.
-          const double* rs = rb + kBand * PAD + ri * 8;                  // this lane's record ri: c, m, (innov), g[0..2][ri]
-          double c_i = rs[0], m_i = rs[1];
-          const double g0 = rs[3], g1 = rs[4], g2 = rs[5];
-          double ad[2 * NC], au[2 * NC];
-#pragma unroll
-          for (int u = 0; u < NC; ++u) {
-            const double2 v2 = pd[16 * u];
-            ad[2 * u] = v2.x;
-            ad[2 * u + 1] = v2.y;
-          }
-#pragma unroll
-          for (int u = 0; u < NC; ++u) {
-            const double2 v2 = pu[16 * u];
-            au[2 * u] = v2.x;
-            au[2 * u + 1] = v2.y;
-          }
-          // d = V d0 (the dots the sequence would have seen), V unit lower triangular: V[i][k] = delta_ik - sum_{t<i} c_t g[t][i] V[t][k];
-          // kb = U d0 with U = diag(c) V; the mean's increment sum_i m_i d_i = w . d0 with w = V^T m.  Lane 16 k + 4 blk + i builds
-          // its own entry (i, k): column k of V lives in the four lanes of a quad, so the recurrence over the rows is three
-          // quad broadcasts; -U[i][k] is then this lane's A operand A[i][k], and w_k (the quad's sum) row 0 of the mean's operand.
-          if (!FULL) {
-            c_i = (ri < nrec) ? c_i : 0.0;
-            m_i = (ri < nrec) ? m_i : 0.0;
-          }
-          double v = (ri == rk) ? 1.0 : 0.0;
-          {
-            const double c0 = quad_bcast<0>(c_i), v0 = quad_bcast<0>(v);
-            v = (ri > 0) ? __builtin_fma(-(c0 * g0), v0, v) : v;
-            const double c1 = quad_bcast<1>(c_i), v1 = quad_bcast<1>(v);
-            v = (ri > 1) ? __builtin_fma(-(c1 * g1), v1, v) : v;
-            const double c2 = quad_bcast<2>(c_i), v2 = quad_bcast<2>(v);
-            v = (ri > 2) ? __builtin_fma(-(c2 * g2), v2, v) : v;
-          }
-          const double uop = -(c_i * v);                                 // -U[ri][rk]   (A[i][k] sits in lane 16 k + 4 blk + i)
-          double wop = group_sum<4>(m_i * v);                            // w_rk
-          wop = (ri == 0) ? wop : 0.0;                                   // row i = 0 of the mean's operand
-          if (!FULL) {
-#pragma unroll
-            for (int t = 0; t < 2 * NC; ++t) {
-              ad[t] = (ri < nrec) ? ad[t] : 0.0;
-              au[t] = (rk < nrec) ? au[t] : 0.0;
-            }
-          }
-          double acc[4] = {0.0, 0.0, 0.0, 0.0};                          // d0[record][row]: D[i = record][j = row], four chains
-#pragma unroll
-          for (int t = 0; t < 2 * NC; ++t) acc[t & 3] = __builtin_amdgcn_mfma_f64_4x4x4f64(ad[t], x[t], acc[t & 3], 0, 0, 0);
-          const double d0 = (acc[0] + acc[1]) + (acc[2] + acc[3]);
-          const double kbn = __builtin_amdgcn_mfma_f64_4x4x4f64(uop, d0, 0.0, 0, 0, 0);    // -kb[record][row]  (:119, :136)
-          xm += __builtin_amdgcn_mfma_f64_4x4x4f64(wop, d0, 0.0, 0, 0, 0);                 // lanes 0..15: sum_k m_k d_k  (:130)
-#pragma unroll
-          for (int t = 0; t < 2 * NC; ++t) x[t] = __builtin_amdgcn_mfma_f64_4x4x4f64(au[t], kbn, x[t], 0, 0, 0);  // :141
-        };
-        EFA_PS(const u64 fb0 = EFA_PS_NOW();)
-        if (nrec == kBand) band(std::true_type());
-        else band(std::false_type());
-        EFA_PS(asm volatile("" : "+v"(x[0]), "+v"(x[1])); fm_cyc += EFA_PS_NOW() - fb0; fm_n += 1;)
-        k += nrec;
-      }
-      if (lane == 0) g_ctl_set(&ctl[cProg + wave], (int)(k - 1));
-      EFA_PS(if (a.dbg != nullptr && lane == 0 && wave == 0 && own0 + 24 < P) { a.dbg[(size_t)(own0 + 24) * 8 + 0] = fm_cyc; a.dbg[(size_t)(own0 + 24) * 8 + 1] = fm_n; a.dbg[(size_t)(own0 + 24) * 8 + 2] = fm_wait; })
-      continue;
-    }
     if (!wait_gt(&ctl[cReady], (int)k, true)) {
       bailed = true;
       break;
     }
     long avail = g_ctl(&ctl[cReady]);  // (read again: reusing the value the wait saw measured slower -- more has usually arrived by now)
+    const long lim = (leads && k < own0) ? own0 : P;
     if (avail > lim) avail = lim;
     if (avail > k + kRingG / 2) avail = k + kRingG / 2;  // progress is reported at least every half ring (slot recycling)
     double ya[2 * NC], yb2[2 * NC];
@@ -1343,16 +1143,9 @@ __global__ __launch_bounds__(kGT) void k_pipe_band(const PipeArgs a) {
   for (; barriers_left > 0; --barriers_left) __syncthreads();
   if (bailed || g_ctl(&ctl[cBail]) != 0) return;  // nothing written back: the host re-runs Phase A
   if (live) {
-    if constexpr (FM) {
-#pragma unroll
-      for (int t = 0; t < 2 * NC; ++t)
-        if (4 * t + kk < M) a.Yp[(size_t)row * M + 4 * t + kk] = x[t];
-      if (kk == 0) a.ym[row] = xm;
-    } else {
-      if (vec) store_row<PLg, NC, true>(a.Yp + (size_t)row * M, M, j, x);
-      else store_row<PLg, NC, false>(a.Yp + (size_t)row * M, M, j, x);
-      if (j == 0) a.ym[row] = xm;
-    }
+    if (vec) store_row<PLg, NC, true>(a.Yp + (size_t)row * M, M, j, x);
+    else store_row<PLg, NC, false>(a.Yp + (size_t)row * M, M, j, x);
+    if (j == 0) a.ym[row] = xm;
   }
 }
 

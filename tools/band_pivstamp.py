@@ -32,12 +32,6 @@ print("pivot loop %.0f cycles per block (%.0f per step), of which waiting for th
 r = [med(lambda b, i=i: t[64 * b + 16, i]) for i in range(5)]
 print("pivot loop per block: band head (ob constants, deferred-Gram wait) %.0f | LDS row loads after the wait %.0f | previous band applied (16 v_readlane pairs + FMA) %.0f | the four steps %.0f | L^-1 store + flags %.0f  (each interval ends in an s_memtime: +100-150 cycles per band each)"
       % (r[4], r[0], r[1], r[2], r[3]))
-fc = np.array([t[64 * b + 24, 0] for b in range(1, nb)], dtype=float); fn = np.array([t[64 * b + 24, 1] for b in range(1, nb)], dtype=float)
-if fn.sum() > 0:
-    print("matrix-core followers (vector wave 0 of each workgroup): %.0f cycles per band of four records (median over workgroups; incl. one s_memtime pair)" % np.median(fc[fn > 0] / fn[fn > 0]))
-    fwt = np.array([t[64 * b + 24, 2] for b in range(1, nb)], dtype=float)
-    sel = fn > 0
-    print("   per workgroup (by position): bands %s ... ; waiting for a whole band, cycles per band: first workgroups %s, last %s" % (fn[sel][:3], np.round(fwt[sel][:4] / fn[sel][:4]), np.round(fwt[sel][-4:] / fn[sel][-4:])))
 for h in (0, 1):
     r = [med(lambda b, i=i: t[64 * b + h, 2 + i]) for i in range(5)]
     print("G wave %d per block: wait first half %.0f | phase 1 %.0f (its operand loads %.0f) | wait band end %.0f | phase 2 %.0f  (sum %.0f)"
