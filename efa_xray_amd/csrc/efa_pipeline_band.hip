@@ -647,15 +647,21 @@ __global__ __launch_bounds__(kGT) void k_pipe_band(const PipeArgs a) {
           // (so that this wave never waits for them); the rest of that band is applied here, in order.
 #pragma unroll
           for (int o = 0; o < kBand - kEarly; ++o) {
+            // the four scalars of a step first, then the four updates: a v_readlane result needs two wait states before a
+            // vector instruction may read it, and back to back (readlane pair, FMA, readlane pair, FMA ...) every FMA paid them
+            double gi[kBand], kbi[kBand];
 #pragma unroll
             for (int s2 = 0; s2 < kBand; ++s2) {
-              const double gi = rl(gprev[o], r0 + s2);
-              const double kbi = GC ? rl(kbprev[o], r0 + s2) : 0.0;
+              gi[s2] = rl(gprev[o], r0 + s2);
+              kbi[s2] = GC ? rl(kbprev[o], r0 + s2) : 0.0;
+            }
+#pragma unroll
+            for (int s2 = 0; s2 < kBand; ++s2) {
               if (GC) {  // the taper makes the downdate two-term: G_ij -= kb_j G_ki + kb_i t_j
-                band[s2] = __builtin_fma(-gi, kbprev[o], band[s2]);
-                band[s2] = __builtin_fma(-kbi, tprev[o], band[s2]);
+                band[s2] = __builtin_fma(-gi[s2], kbprev[o], band[s2]);
+                band[s2] = __builtin_fma(-kbi[s2], tprev[o], band[s2]);
               } else {
-                band[s2] = __builtin_fma(-gi, gamprev[o], band[s2]);  // gamprev holds the VECTOR gamma g: one product per step, not per row
+                band[s2] = __builtin_fma(-gi[s2], gamprev[o], band[s2]);  // gamprev holds the VECTOR gamma g: one product per step, not per row
               }
             }
           }
@@ -694,17 +700,21 @@ __global__ __launch_bounds__(kGT) void k_pipe_band(const PipeArgs a) {
               const double gam = cc * __builtin_fma(-cc, Gkk, 2.0);
               const double tj = GC ? __builtin_fma(-kb, Gkk, g) : 0.0;      // t_j = G_kj - kb_j G_kk
               const double gg = gam * g;                                    // the step's downdate of row i is G_ki (gamma g)
+              double gi[kBand], kbi[kBand];                                  // (all the scalars first: see the note on wait states above)
 #pragma unroll
               for (int s2 = s + 1; s2 < kBand; ++s2) {
-                const double gi = rl(g, r0 + s2);                           // G_k,i of row i = r0 + s2
-                if (GC) {  // kb_j = w_kj c G_kj is no longer a multiple of G_kj: the two-term form, kb_i by v_readlane
-                  const double kbi = rl(kb, r0 + s2);
-                  band[s2] = __builtin_fma(-gi, kb, band[s2]);
-                  band[s2] = __builtin_fma(-kbi, tj, band[s2]);
-                  linv[s2] = __builtin_fma(-kbi, linv[s], linv[s2]);        // L[s2][s] = kb_i
+                gi[s2] = rl(g, r0 + s2);                                    // G_k,i of row i = r0 + s2
+                kbi[s2] = GC ? rl(kb, r0 + s2) : 0.0;                       // GC: kb_j = w_kj c G_kj is no longer a multiple of G_kj
+              }
+#pragma unroll
+              for (int s2 = s + 1; s2 < kBand; ++s2) {
+                if (GC) {  // the two-term form, kb_i by v_readlane
+                  band[s2] = __builtin_fma(-gi[s2], kb, band[s2]);
+                  band[s2] = __builtin_fma(-kbi[s2], tj, band[s2]);
+                  linv[s2] = __builtin_fma(-kbi[s2], linv[s], linv[s2]);    // L[s2][s] = kb_i
                 } else {
-                  band[s2] = __builtin_fma(-gi, gg, band[s2]);
-                  linv[s2] = __builtin_fma(-(cc * gi), linv[s], linv[s2]);  // L[s2][s] = kb_i = c G_k,i
+                  band[s2] = __builtin_fma(-gi[s2], gg, band[s2]);
+                  linv[s2] = __builtin_fma(-(cc * gi[s2]), linv[s], linv[s2]);  // L[s2][s] = kb_i = c G_k,i
                 }
               }
               recb[s * kRowsWG] = make_double2(g, kb);         // the step's record: {G_kj, kb_j} per row
