@@ -244,10 +244,10 @@ __global__ __launch_bounds__(kGT) void k_pipe_band(const PipeArgs a) {
 #else
 #define EFA_HO(row, slot) do { } while (0)
 #endif
-#ifdef EFA_PIPE_PIVSTAMP  /* make pivstamp: wait / work accounting of the pivot and G waves only (they have registers to spare) */
+#if defined(EFA_PIPE_PIVSTAMP) && !defined(EFA_PIPE_HOSTAMP_ONLY)  /* make pivstamp: wait / work accounting of the pivot and G waves only (they have registers to spare) */
 #define EFA_PS_NOW() __builtin_amdgcn_s_memtime()
 #define EFA_PS(stmt) stmt
-#else
+#else  /* (make hostamp: only the eight s_memrealtime stamps of the hand-over chain per block -- next to no perturbation) */
 #define EFA_PS_NOW() 0ull
 #define EFA_PS(stmt)
 #endif
@@ -392,6 +392,7 @@ __global__ __launch_bounds__(kGT) void k_pipe_band(const PipeArgs a) {
           __builtin_amdgcn_s_sleep(2);
           continue;
         }
+        if (leads && next + cnt == own0 && limit == own0) EFA_HO(8, 7);  // T2a: this (next) leader's loader has SEEN the last foreign record complete
         const long need = next + cnt - 1 - kRingG;  // slots are recycled only once every vector wave consumed them
         if (need >= 0) {
           for (;;) {
@@ -1040,6 +1041,8 @@ __global__ __launch_bounds__(kGT) void k_pipe_band(const PipeArgs a) {
               ye0[J] = yt[0];
             }
             // D[s = 4 v + lr][col = lc]: register 0 holds ye_{r0 + lr}, which is also B[k = lr][j = lc] of the update
+            // (v_mfma_f64_4x4x4_4b would form exactly these four rows in a quarter of the matrix-core time, operands and result in
+            //  these very lanes -- measured 4 % SLOWER overall, 4.53 vs 4.33 ms, although the rows leave 4 k cycles earlier)
             {  // the ye part of the band's records, straight to the trajectory (its scalars come from the forwarder wave)
               u64* grec = a.traj + (size_t)(own0 + r0 + ((lr < s1) ? lr : 0)) * TS;
               if (lr < s1) {
@@ -1048,6 +1051,7 @@ __global__ __launch_bounds__(kGT) void k_pipe_band(const PipeArgs a) {
                   if (16 * J + lc < PAD) g_traj_store(grec + 16 * J + lc, ye0[J]);
               }
             }
+            if (b == nbands - 1) EFA_HO(8, 6);  // T1b: the ye rows of the block's last band are on their way to global memory
 #pragma unroll
             for (int J = 0; J < NJ; ++J)
               if (16 * J + lc < PAD) ring[(size_t)((own0 + r0 + lr) % kRingG) * TSR + 16 * J + lc] = ye0[J];

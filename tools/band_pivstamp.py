@@ -39,15 +39,21 @@ for h in (0, 1):
 # the hand-over chain between consecutive blocks, absolute s_memrealtime stamps (10 ns ticks) in row own0 + 8
 rt = lambda b, c: int(t[64 * b + 8, c])
 ch = []
+ch2 = []
 for b in range(2, nb - 2):
     T0, T1 = rt(b, 5), rt(b, 1)                                   # leader b: pivot done, last record forwarded
     T2, T3, T4, T5 = rt(b + 1, 0), rt(b + 1, 2), rt(b + 1, 3), rt(b + 1, 4)   # leader b+1
     if min(T0, T1, T2, T3, T4, T5) > 0:
         ch.append((T1 - T0, T2 - T1, T3 - T2, T4 - T3, T5 - T4, T5 - T0, rt(b + 1, 5) - T5))
+        if rt(b, 6) > 0 and rt(b + 1, 7) > 0:
+            ch2.append((rt(b, 6) - T0, rt(b + 1, 7) - rt(b, 6), T2 - rt(b + 1, 7)))
 ch = np.array(ch) * 10.0 * 2.39   # -> shader cycles at 2.39 GHz
 if len(ch):
     print("hand-over chain (median cycles): pivot done -> last record forwarded %.0f | -> in next leader's ring %.0f | -> its rows parked (B1) %.0f | -> Gram done (B2) %.0f | -> its pivot starts %.0f ;  total %.0f ; its pivot loop %.0f"
           % tuple(np.median(ch, axis=0)))
+if len(ch2):
+    c2 = np.median(np.array(ch2) * 10.0 * 2.39, axis=0)
+    print("   of which: pivot done -> last band's ye rows stored by its owner wave %.0f | -> seen complete by the next leader's loader %.0f | -> in its ring (ring space, LDS writes) %.0f" % tuple(c2))
 # per band (rows own0+64+b of the NEXT block's stamp rows hold band b of block own0): absolute s_memtime stamps
 ev = []
 for blk in range(2, nb - 2):
