@@ -54,7 +54,8 @@ constexpr int kVW = 4;        // vector waves (quad per row, one per SIMD)
 constexpr int kGT = 512;      // threads: 4 vector + pivot + 2 G waves + loader
 constexpr int PLg = kPipeLanes;  // lanes per row: same record layout as efa_pipeline.hip
 constexpr int kRingG = 16;    // LDS ring slots for ye rows (four bands; 8 and 32 slots measure the same)
-constexpr int kPollG = 4;
+constexpr int kPollGMax = 8;  // records per poll of the loader wave: two bands without localisation (it must be able to catch up: a poll is a
+                              // global round trip), one band with (each record also brings its row of the obs-obs taper table)
 constexpr int kRowsWG = kPipeRowsPerWG;  // 64
 #ifndef EFA_BAND
 #define EFA_BAND 4
@@ -197,6 +198,7 @@ __global__ __launch_bounds__(kGT) void k_pipe_band(const PipeArgs a) {
   double* Yt = U;
   double2* s_gk = reinterpret_cast<double2*>(U);  // [step][row] = {G_kj, kb_j}
   constexpr bool DEFER = Sh::kDefer;
+  constexpr int kPollG = GC ? 4 : kPollGMax;
   // record of step st (per-lane or uniform st)
   auto SG = [&](int st) -> double2* { return (DEFER && st < Sh::kSgE) ? sgk_e + (size_t)st * kRowsWG : s_gk + (size_t)st * kRowsWG; };
 
@@ -298,7 +300,7 @@ __global__ __launch_bounds__(kGT) void k_pipe_band(const PipeArgs a) {
   };
   // least-advanced consumer of the ye ring: the 4 vector waves and the forwarder
   auto min_prog = [&]() {
-    int mn = min(g_ctl_lane(&ctl[cProg + (lane & 3)]), g_ctl_lane(&ctl[cFwd]));
+    int mn = g_ctl_lane(&ctl[cProg + (lane & 3)]);  // (the forwarder reads the ring no more: the four vector waves are its only consumers)
     mn = min(mn, __builtin_amdgcn_mov_dpp(mn, 0xB1, 0xF, 0xF, true));
     mn = min(mn, __builtin_amdgcn_mov_dpp(mn, 0x4E, 0xF, 0xF, true));
     return __builtin_amdgcn_readfirstlane(mn);
@@ -466,7 +468,6 @@ __global__ __launch_bounds__(kGT) void k_pipe_band(const PipeArgs a) {
       // with four stores from the band's own lanes.  (The followers validate every word of a record by itself, so its two parts
       // may arrive in either order.)  Before, this wave read every ye row back from the ring and stored it: as slow as the pivot,
       // and its backlog was the first 4-7 k cycles of every hand-over.
-      if (lane == 0) g_ctl_set(&ctl[cFwd], 0x7fffffff);  // (not a consumer of the ring any more)
       u64* const rec_l = a.traj + (size_t)(own0 + (f_ob ? lane : 0)) * TS + PAD;  // this lane's ob: its record's scalars
       for (int b = 0; b < nbands && !failed; ++b) {
         const int s1 = (nb - kBand * b < kBand) ? nb - kBand * b : kBand;
@@ -745,6 +746,7 @@ __global__ __launch_bounds__(kGT) void k_pipe_band(const PipeArgs a) {
           g_ctl_set(&ctl[cSReady], r0 + s1);
           g_ctl_set(&ctl[cLinv], b + 1);
         }
+        if ((b & 3) == 3) EFA_HO(14, b >> 2);  // the pivot is through with bands 3, 7, 11, 15
         EFA_PS(ps_en += EFA_PS_NOW() - ps_s1;)
       }
       EFA_PS(if (a.dbg != nullptr && lane == 0 && own0 + 16 < P) {
@@ -870,6 +872,7 @@ __global__ __launch_bounds__(kGT) void k_pipe_band(const PipeArgs a) {
             update_row(std::integral_constant<int, 3>(), kBand * bb, 0, kBand);
           }
           rows_ready = true;
+          __builtin_amdgcn_s_setprio(0);  // (the priority was for the time the vector wave on this SIMD formed deferred tiles back to back)
         }
         load_b(r0, 0, kBand);
         switch (I2) {
@@ -998,17 +1001,24 @@ __global__ __launch_bounds__(kGT) void k_pipe_band(const PipeArgs a) {
       // from the same registers.  Nothing on this chain waits for another vector wave (no parking, no second counter);
       // the three other waves take the band from the ring when the owner's flag says it is there.
       static_assert(kBand == 4, "band ownership: four bands per 16-row tile");
+      // Which 16 rows (bands 4 g .. 4 g + 3) a wave takes: wave 0 the first group, then wave 3, then waves 1 and 2.  The four
+      // waves move through the bands in lock step (a band's owner publishes its YE, the others apply it), and with the deferred
+      // Gram matrix waves 1 and 2 start the block ~10 k cycles late (four tiles each), wave 3 ~4.5 k (two), wave 0 at once:
+      // while wave 1 owned bands 4..7 the whole group stood at band 4 until it arrived -- light stamps: every wave ~10 k cycles
+      // behind the pivot from band 7 on, 13 k at the end of the block, the largest piece of the hand-over.  Now the late
+      // waves own the late bands and catch up, as consumers, on what the early ones publish.
+      const int grpw = DEFER ? ((wave == 0) ? 0 : (wave == 3) ? 1 : (wave == 1) ? 2 : 3) : wave;
       v4f64 xt[NJ];
       const int lr = lane >> 4, lc = lane & 15;
 #pragma unroll
       for (int J = 0; J < NJ; ++J)
 #pragma unroll
-        for (int v = 0; v < 4; ++v) xt[J][v] = Yt[(size_t)(16 * wave + 4 * v + lr) * SP + 16 * J + lc];
+        for (int v = 0; v < 4; ++v) xt[J][v] = Yt[(size_t)(16 * grpw + 4 * v + lr) * SP + 16 * J + lc];
       __syncthreads();  // B2: G complete; the tile region now belongs to the pivot wave's records
       barriers_left = 1;
       if (DEFER) gram_deferred();  // (the tile region stays the parked rows until cDef says all twelve tiles are done)
       for (int b4 = 0; b4 < nbands && !bailed; b4 += 4) {
-        const bool owner = (b4 >> 2) == wave;
+        const bool owner = (b4 >> 2) == grpw;
 #pragma unroll
         for (int vb = 0; vb < 4; ++vb) {  // vb = band & 3: the owner's register holding the band's rows (static index)
           const int b = b4 + vb;
@@ -1018,22 +1028,36 @@ __global__ __launch_bounds__(kGT) void k_pipe_band(const PipeArgs a) {
           // ring slots of this band are those of the band kRingG obs earlier: every consumer must be through with them
           // (checked by the owner before it writes; the others only read)
           double ye0[NJ];  // the owner's YE tiles: register 0 of each MFMA result
+          double av_own = 0.0;
           if (owner) {
-            if (!wait_gt(&ctl[cLinv], b, true)) {  // the pivot wave has finished the band
-              bailed = true;
-              break;
-            }
-            if (b >= kRingG / kBand) {
-              const int need = (int)(own0 + kBand * (b - kRingG / kBand) + kBand - 1);
-              while (min_prog() < need) {
-                if (g_ctl(&ctl[cBail]) != 0 || --budget <= 0 || ((budget & 15) == 0 && EFA_TIMED_OUT())) {
-                  bailed = true;
-                  break;
+            if (b == nbands - 1) EFA_HO(9, 0);  // the owner of the last band is ready for it (has finished the bands before)
+            // ONE poll for both conditions -- the pivot has finished the band (cLinv) and the band's ring slots are free (every
+            // consumer through with the band four bands earlier): the four vector waves move through the bands in lock step
+            // at about the pivot's own pace, so every LDS round trip on this path is a round trip per band of lag.
+            {
+              const int need = (b >= kRingG / kBand) ? (int)(own0 + kBand * (b - kRingG / kBand) + kBand - 1) : -0x7fffffff;
+              for (;;) {
+                const int fl = g_ctl_lane(&ctl[cLinv]);
+                const int mp = min_prog();
+                if (__builtin_amdgcn_readfirstlane(fl) > b && mp >= need) break;
+                if ((++polls & 15) == 0) {
+                  if (g_ctl(&ctl[cBail]) != 0) {
+                    bailed = true;
+                    break;
+                  }
+                  budget -= 16;
+                  if (budget <= 0 || EFA_TIMED_OUT()) {
+                    give_up();
+                    bailed = true;
+                    break;
+                  }
                 }
               }
               if (bailed) break;
             }
+            if (b == nbands - 1) EFA_HO(9, 2);  // ... the pivot's flag is up and there is ring space
             const double aop = (lc < kBand) ? LinvA[((size_t)b * kBand + lr) * kBand + lc] : 0.0;  // A[s = lc][t = lr], rows s >= 4 are zero
+            av_own = SG((lr < s1) ? r0 + lr : r0)[16 * grpw + lc].y;  // (the update's kb operand, fetched in the same LDS round trip)
 #pragma unroll
             for (int J = 0; J < NJ; ++J) {
               const v4f64 z = {0.0, 0.0, 0.0, 0.0};
@@ -1066,7 +1090,7 @@ __global__ __launch_bounds__(kGT) void k_pipe_band(const PipeArgs a) {
           {
             const int st = r0 + lr;  // this lane's K slice: step st
             const bool valid = lr < s1;
-            double av = SG(valid ? st : r0)[16 * wave + lc].y;
+            double av = owner ? av_own : SG(valid ? st : r0)[16 * grpw + lc].y;
             av = valid ? -av : 0.0;
             const double* bs = ring + (size_t)((own0 + (valid ? st : r0)) % kRingG) * TSR;
 #pragma unroll
@@ -1077,6 +1101,7 @@ __global__ __launch_bounds__(kGT) void k_pipe_band(const PipeArgs a) {
             }
           }
           if (lane == 0) g_ctl_set(&ctl[cProg + wave], (int)(own0 + r0 + s1 - 1));  // ring slots up to here consumed
+          if ((b & 3) == 3) EFA_HO(10 + wave, b >> 2);  // this vector wave is through with bands 3, 7, 11, 15
         }
       }
       EFA_BLOCKSTAMP(wave == 0 && lane == 0, 6);
@@ -1089,7 +1114,7 @@ __global__ __launch_bounds__(kGT) void k_pipe_band(const PipeArgs a) {
       for (int J = 0; J < NJ; ++J)
 #pragma unroll
         for (int v = 0; v < 4; ++v)
-          if (16 * J + lc < PAD) Yt[(size_t)(16 * wave + 4 * v + lr) * SP + 16 * J + lc] = xt[J][v];
+          if (16 * J + lc < PAD) Yt[(size_t)(16 * grpw + 4 * v + lr) * SP + 16 * J + lc] = xt[J][v];
       if (lane == 0) __hip_atomic_fetch_add(&ctl[cPark], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
       if (!wait_gt(&ctl[cPark], kVW - 1, false)) {
         bailed = true;

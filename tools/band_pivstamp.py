@@ -51,6 +51,24 @@ ch = np.array(ch) * 10.0 * 2.39   # -> shader cycles at 2.39 GHz
 if len(ch):
     print("hand-over chain (median cycles): pivot done -> last record forwarded %.0f | -> in next leader's ring %.0f | -> its rows parked (B1) %.0f | -> Gram done (B2) %.0f | -> its pivot starts %.0f ;  total %.0f ; its pivot loop %.0f"
           % tuple(np.median(ch, axis=0)))
+ow = []
+for b in range(2, nb - 2):
+    T0 = rt(b, 5)
+    r9 = [int(t[64 * b + 9, c]) for c in range(3)]
+    if T0 > 0 and min(r9) > 0 and rt(b, 6) > 0:
+        ow.append((r9[0] - T0, r9[1] - T0, r9[2] - T0, rt(b, 6) - T0))
+if len(ow):
+    print("   owner wave of the last band, cycles after the pivot finished: ready for the band %.0f | saw the pivot's flag %.0f | has ring space %.0f | ye rows stored %.0f" % tuple(np.median(np.array(ow) * 10.0 * 2.39, axis=0)))
+lag = []
+for b in range(2, nb - 2):
+    pv = [int(t[64 * b + 14, c]) for c in range(4)]
+    vw = [[int(t[64 * b + 10 + w, c]) for c in range(4)] for w in range(4)]
+    if min(pv) > 0 and min(min(v) for v in vw) > 0:
+        lag.append([[vw[w][c] - pv[c] for c in range(4)] for w in range(4)])
+if len(lag):
+    L = np.median(np.array(lag) * 10.0 * 2.39, axis=0)
+    for w in range(4):
+        print("   vector wave %d is through with bands 3 / 7 / 11 / 15 this many cycles after the pivot: %s" % (w, np.round(L[w])))
 if len(ch2):
     c2 = np.median(np.array(ch2) * 10.0 * 2.39, axis=0)
     print("   of which: pivot done -> last band's ye rows stored by its owner wave %.0f | -> seen complete by the next leader's loader %.0f | -> in its ring (ring space, LDS writes) %.0f" % tuple(c2))
