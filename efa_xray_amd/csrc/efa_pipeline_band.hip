@@ -243,8 +243,10 @@ __global__ __launch_bounds__(kGT) void k_pipe_band(const PipeArgs a) {
 #endif
 #ifdef EFA_PIPE_PIVSTAMP
 #define EFA_HO(row, slot) do { if (a.dbg != nullptr && lane == 0 && own0 + (row) < P) a.dbg[(size_t)(own0 + (row)) * 8 + (slot)] = __builtin_amdgcn_s_memrealtime(); } while (0)
+#define EFA_HO_IF(cond, row, slot) do { if (cond) EFA_HO(row, slot); } while (0)
 #else
 #define EFA_HO(row, slot) do { } while (0)
+#define EFA_HO_IF(cond, row, slot) do { } while (0)  /* (nothing of the condition either: dead tests perturbed the register allocation) */
 #endif
 #if defined(EFA_PIPE_PIVSTAMP) && !defined(EFA_PIPE_HOSTAMP_ONLY)  /* make pivstamp: wait / work accounting of the pivot and G waves only (they have registers to spare) */
 #define EFA_PS_NOW() __builtin_amdgcn_s_memtime()
@@ -394,7 +396,7 @@ __global__ __launch_bounds__(kGT) void k_pipe_band(const PipeArgs a) {
           __builtin_amdgcn_s_sleep(2);
           continue;
         }
-        if (leads && next + cnt == own0 && limit == own0) EFA_HO(8, 7);  // T2a: this (next) leader's loader has SEEN the last foreign record complete
+        EFA_HO_IF(leads && next + cnt == own0 && limit == own0, 8, 7);  // T2a: this (next) leader's loader has SEEN the last foreign record complete
         const long need = next + cnt - 1 - kRingG;  // slots are recycled only once every vector wave consumed them
         if (need >= 0) {
           for (;;) {
@@ -426,7 +428,7 @@ __global__ __launch_bounds__(kGT) void k_pipe_band(const PipeArgs a) {
       }
     };
     follow(0, (own0 < P) ? own0 : P);
-    if (leads) EFA_HO(8, 0);   // T2: the last foreign record is in this workgroup's ring
+    EFA_HO_IF(leads, 8, 0);   // T2: the last foreign record is in this workgroup's ring
     EFA_BLOCKSTAMP(lane == 0 && leads, 3);
     EFA_WAIT_OUT(lane == 0 && leads, 4, 6, __builtin_amdgcn_s_memrealtime());  // 100 MHz, comparable across workgroups
 #ifdef EFA_PIPE_BLOCKTIME
@@ -577,11 +579,11 @@ __global__ __launch_bounds__(kGT) void k_pipe_band(const PipeArgs a) {
       }
     }
     __syncthreads();  // B1
-    if (wave == kVW) EFA_HO(8, 2);   // T3: every vector wave has parked its rows
+    EFA_HO_IF(wave == kVW, 8, 2);   // T3: every vector wave has parked its rows
     if (DEFER) gram_tile(0, wave - kVW);
     else form_gram();
     __syncthreads();  // B2
-    if (wave == kVW) EFA_HO(8, 3);   // T4: G is complete
+    EFA_HO_IF(wave == kVW, 8, 3);   // T4: G is complete
     if (wave == kVW) {
       // ---------------- pivot wave: lane j <-> column j of G ----------------
       __builtin_amdgcn_s_setprio(3);  // the serial chain: ahead of the vector wave that shares its SIMD
@@ -746,7 +748,7 @@ __global__ __launch_bounds__(kGT) void k_pipe_band(const PipeArgs a) {
           g_ctl_set(&ctl[cSReady], r0 + s1);
           g_ctl_set(&ctl[cLinv], b + 1);
         }
-        if ((b & 3) == 3) EFA_HO(14, b >> 2);  // the pivot is through with bands 3, 7, 11, 15
+        EFA_HO_IF((b & 3) == 3, 14, b >> 2);  // the pivot is through with bands 3, 7, 11, 15
         EFA_PS(ps_en += EFA_PS_NOW() - ps_s1;)
       }
       EFA_PS(if (a.dbg != nullptr && lane == 0 && own0 + 16 < P) {
@@ -1030,7 +1032,7 @@ __global__ __launch_bounds__(kGT) void k_pipe_band(const PipeArgs a) {
           double ye0[NJ];  // the owner's YE tiles: register 0 of each MFMA result
           double av_own = 0.0;
           if (owner) {
-            if (b == nbands - 1) EFA_HO(9, 0);  // the owner of the last band is ready for it (has finished the bands before)
+            EFA_HO_IF(b == nbands - 1, 9, 0);  // the owner of the last band is ready for it (has finished the bands before)
             // ONE poll for both conditions -- the pivot has finished the band (cLinv) and the band's ring slots are free (every
             // consumer through with the band four bands earlier): the four vector waves move through the bands in lock step
             // at about the pivot's own pace, so every LDS round trip on this path is a round trip per band of lag.
@@ -1055,7 +1057,7 @@ __global__ __launch_bounds__(kGT) void k_pipe_band(const PipeArgs a) {
               }
               if (bailed) break;
             }
-            if (b == nbands - 1) EFA_HO(9, 2);  // ... the pivot's flag is up and there is ring space
+            EFA_HO_IF(b == nbands - 1, 9, 2);  // ... the pivot's flag is up and there is ring space
             const double aop = (lc < kBand) ? LinvA[((size_t)b * kBand + lr) * kBand + lc] : 0.0;  // A[s = lc][t = lr], rows s >= 4 are zero
             av_own = SG((lr < s1) ? r0 + lr : r0)[16 * grpw + lc].y;  // (the update's kb operand, fetched in the same LDS round trip)
 #pragma unroll
@@ -1075,7 +1077,7 @@ __global__ __launch_bounds__(kGT) void k_pipe_band(const PipeArgs a) {
                   if (16 * J + lc < PAD) g_traj_store(grec + 16 * J + lc, ye0[J]);
               }
             }
-            if (b == nbands - 1) EFA_HO(8, 6);  // T1b: the ye rows of the block's last band are on their way to global memory
+            EFA_HO_IF(b == nbands - 1, 8, 6);  // T1b: the ye rows of the block's last band are on their way to global memory
 #pragma unroll
             for (int J = 0; J < NJ; ++J)
               if (16 * J + lc < PAD) ring[(size_t)((own0 + r0 + lr) % kRingG) * TSR + 16 * J + lc] = ye0[J];
@@ -1101,7 +1103,7 @@ __global__ __launch_bounds__(kGT) void k_pipe_band(const PipeArgs a) {
             }
           }
           if (lane == 0) g_ctl_set(&ctl[cProg + wave], (int)(own0 + r0 + s1 - 1));  // ring slots up to here consumed
-          if ((b & 3) == 3) EFA_HO(10 + wave, b >> 2);  // this vector wave is through with bands 3, 7, 11, 15
+          EFA_HO_IF((b & 3) == 3, 10 + wave, b >> 2);  // this vector wave is through with bands 3, 7, 11, 15
         }
       }
       EFA_BLOCKSTAMP(wave == 0 && lane == 0, 6);
