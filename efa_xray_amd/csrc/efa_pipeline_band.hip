@@ -390,10 +390,23 @@ __global__ __launch_bounds__(kGT) void k_pipe_band(const PipeArgs a) {
           if (cnt == d && d < nrec && __all(ok)) cnt = d + 1;
         }
         if (cnt == 0) {
-          if (--budget <= 0 || __hip_atomic_load(a.status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0 ||
-              ((budget & 15) == 0 && EFA_TIMED_OUT()))
-            failed = true;
-          __builtin_amdgcn_s_sleep(2);
+          // Nothing yet: wait on ONE word -- the last ye word of the first missing record, which its owner wave stores with its
+          // last store instruction -- and poll the full records again when it has arrived.  A full poll is sixteen loads per
+          // lane and a global round trip; missing the records by a moment cost a whole such period (light stamps: the next
+          // leader's loader saw the last records 5 k cycles after they had been stored).
+          const u64* probe = a.traj + (size_t)next * TS + (PAD - 1);
+          for (;;) {
+            if (--budget <= 0 || __hip_atomic_load(a.status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0 ||
+                ((budget & 15) == 0 && EFA_TIMED_OUT())) {
+              failed = true;
+              break;
+            }
+            const u64 w = g_traj_load(probe);
+            const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)(w & 0xffffffffull));
+            const unsigned hi = __builtin_amdgcn_readfirstlane((unsigned)(w >> 32));
+            if ((((u64)hi << 32) | lo) != kTrajSentinel) break;
+            __builtin_amdgcn_s_sleep(1);
+          }
           continue;
         }
         EFA_HO_IF(leads && next + cnt == own0 && limit == own0, 8, 7);  // T2a: this (next) leader's loader has SEEN the last foreign record complete
