@@ -1096,7 +1096,7 @@ __global__ __launch_bounds__(kGT) void k_pipe_band(const PipeArgs a) {
               if (16 * J + lc < PAD) ring[(size_t)((own0 + r0 + lr) % kRingG) * TSR + 16 * J + lc] = ye0[J];
             if (lane == 0) g_ctl_set(&ctl[cYe], 4 * (b + 1));  // the other vector waves may read the band
           } else {
-            if (!wait_gt(&ctl[cYe], 4 * (b + 1) - 1, false)) {
+            if (!wait_gt(&ctl[cYe], 4 * (b + 1) - 1, true)) {
               bailed = true;
               break;
             }
