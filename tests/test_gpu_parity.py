@@ -979,3 +979,31 @@ def test_persistent_phase_a_falls_back_within_a_bound_when_the_device_is_occupie
         ctx.set_option("spin_ms", -1)
         ctx.set_option("pipeline", 1)
         ctx.set_option("path", 0)
+
+
+@pytest.mark.gpu
+def test_gc_sweep_random_shapes_vs_oracle():
+    """Sixteen random (members, slabs, columns, obs) shapes through both forms of the one-pass localised sweep -- prior members
+    in / posterior members out (efa_state_cycle_dev) and perturbations + means (the array API) -- against the oracle:
+    member counts that are and are not a multiple of 4 (the row-per-lane kernel pads), slab counts around the groups of 16,
+    column counts that are not a multiple of the 16-column block."""
+    rng = np.random.default_rng(2026)
+    for it in range(16):
+        M = int(rng.choice([2, 4, 6, 10, 18, 34, 50, 66, 80, 98, 100, 102, 104]))
+        n_lead, ncol, P = int(rng.integers(1, 41)), int(rng.integers(17, 140)), int(rng.integers(5, 70))
+        N = n_lead * ncol
+        c = _random_case(5000 + it, N, M, P, True, ncol=ncol)
+        c["hw"][:] = rng.uniform(300, 4000, P)
+        xam, Xap, diag = _run_oracle(c)
+        ctx = _ctx()
+        X = ctx.to_device(c["X"])
+        Yp = ctx.to_device(c["HX"])
+        ym = ctx.empty((P,))
+        ctx.form_perts(P, M, Yp, ym, Yp)
+        ctx.obs_phase(M, P, ym, Yp, c["val"], c["err"], c["asm"], 1, c["ob_lat"], c["ob_lon"], c["hw"])
+        post = ctx.empty((N, M))
+        ctx.state_cycle(N, M, X, post, c["lat"].reshape(-1), c["lon"].reshape(-1), c["n_lead"])
+        assert_parity(post.download(), orc.format_posterior_state(xam, Xap, N), "post, case %d (M=%d, slabs=%d, columns=%d)" % (it, M, n_lead, ncol))
+        h_xam, h_Xap, _ = _run_hip(c, path="sweep")
+        assert_parity(h_Xap, Xap, "Xap, case %d" % it)
+        assert_parity(h_xam, xam, "xam, case %d" % it)
