@@ -94,6 +94,28 @@ def test_no_cpu_fallback_without_gpu():
         EnSRF(st, [ob], verbose=False).update()
 
 
+def test_host_side_of_the_c_abi_under_address_and_ub_sanitizers():
+    """SURVEY.md section 5's sanitizer row, on the CPU build only (no GPU sanitizers on this pool): the host side of the C ABI compiled
+    with -fsanitize=address,undefined (make asan; device code as in the product), every entry point's argument checks walked in a
+    child process under the preloaded clang ASan runtime.  A sanitizer report aborts the child."""
+    import glob
+    csrc = os.path.join(ROOT, "efa_xray_amd", "csrc")
+    lib = os.path.join(ROOT, "efa_xray_amd", "libefa_hip_asan.so")
+    srcs = glob.glob(os.path.join(csrc, "*.hip")) + glob.glob(os.path.join(csrc, "*.h")) + [os.path.join(ROOT, "include", "efa_hip.h")]
+    if not os.path.exists(lib) or os.path.getmtime(lib) < max(os.path.getmtime(f) for f in srcs):
+        subprocess.check_call(["make", "-C", csrc, "asan", "-j", str(min(8, os.cpu_count() or 1))], stdout=subprocess.DEVNULL)
+    rt = glob.glob("/opt/rocm/lib/llvm/lib/clang/*/lib/linux/libclang_rt.asan-x86_64.so")
+    if not rt:
+        pytest.skip("clang ASan runtime not found")
+    env = dict(os.environ, LD_PRELOAD=rt[0], ASAN_OPTIONS="detect_leaks=0:halt_on_error=1:abort_on_error=0:protect_shadow_gap=0",
+               UBSAN_OPTIONS="halt_on_error=1:print_stacktrace=1")
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "_asan_abi_driver.py"), lib], env=env,
+                         stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=300)
+    text = out.stdout.decode("utf-8", "replace")
+    assert out.returncode == 0 and "asan-abi-ok" in text, text[-3000:]
+    assert "AddressSanitizer" not in text and "runtime error" not in text, text[-3000:]
+
+
 def test_missing_library_fails_loudly(tmp_path):
     from efa_xray_amd import _lib
     with pytest.raises(RuntimeError, match="not built"):
