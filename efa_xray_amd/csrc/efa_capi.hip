@@ -170,6 +170,9 @@ struct efa_ctx {
   hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
   double state_ms = 0.0, obs_ms = 0.0;
   bool obs_ms_pending = false;  // ev[0] .. ev[1] of the last obs phase not read yet
+  bool state_ms_pending = false;  // timing 2: ev[2] .. ev[3] of the last state phase not read yet
+  double state_ms_sum = 0.0, obs_ms_sum = 0.0;  // timing 2: sums since the previous efa_last_timing
+  long state_launches_sum = 0;
   long state_launches = 0;
   int path_taken = 0;
 };
@@ -177,6 +180,41 @@ struct efa_ctx {
 namespace {
 
 using namespace efa;
+
+// "timing" 2 (deferred): no phase call waits for its own events -- the host may run ahead of the device from one cycle into the
+// next.  An interval is read when its events are about to be recorded again (the calls in between have synchronised the stream
+// since: the wait returns at once) or in efa_last_timing, and added to running sums.
+void harvest_obs_ms(efa_ctx* c) {
+  if (!c->obs_ms_pending) return;
+  float ms = 0.f;
+  if (hipEventSynchronize(c->ev[1]) == hipSuccess && hipEventElapsedTime(&ms, c->ev[0], c->ev[1]) == hipSuccess) {
+    c->obs_ms = ms;
+    c->obs_ms_sum += ms;
+  } else {
+    (void)hipGetLastError();
+  }
+  c->obs_ms_pending = false;
+}
+void harvest_state_ms(efa_ctx* c) {
+  if (!c->state_ms_pending) return;
+  float ms = 0.f;
+  if (hipEventSynchronize(c->ev[3]) == hipSuccess && hipEventElapsedTime(&ms, c->ev[2], c->ev[3]) == hipSuccess) {
+    c->state_ms = ms;
+    c->state_ms_sum += ms;
+  } else {
+    (void)hipGetLastError();
+  }
+  c->state_ms_pending = false;
+}
+// end of a state-phase call: timing 1 waits and reads, timing 2 leaves the interval pending
+int finish_state_timing(efa_ctx* c, hipStream_t s) {
+  c->state_launches_sum += c->state_launches;
+  if (!c->timing) return EFA_OK;
+  EFA_HIP(hipEventRecord(c->ev[3], s));
+  c->state_ms_pending = true;
+  if (c->timing == 1) harvest_state_ms(c);
+  return EFA_OK;
+}
 
 int use(efa_ctx* c) {
   if (!c) return fail(EFA_ERR_INVALID, "null context");
@@ -222,8 +260,8 @@ int obs_phase(efa_ctx* c, int M, long P, double* ym_dev, double* Yp_dev, const d
   c->loc_mode = loc_mode;
   c->n_active = 0;
   c->have_transform = false;
+  harvest_obs_ms(c);
   c->obs_ms = 0.0;
-  c->obs_ms_pending = false;
   if (P == 0) {
     c->have_traj = true;
     c->h_assim.clear();
@@ -735,6 +773,7 @@ int state_phase(efa_ctx* c, long rows, int M, const double* xm_in, const double*
   if (!c->have_traj) return fail(EFA_ERR_INVALID, "efa_state_phase_dev called before efa_obs_phase_dev");
   if (M != c->M) return fail(EFA_ERR_INVALID, "M=%d differs from the obs phase's M=%d", M, c->M);
   if (rows < 0) return fail(EFA_ERR_INVALID, "negative row count");
+  harvest_state_ms(c);
   c->state_ms = 0.0;
   c->state_launches = 0;
   c->path_taken = EFA_PATH_SWEEP;
@@ -760,13 +799,7 @@ int state_phase(efa_ctx* c, long rows, int M, const double* xm_in, const double*
   } else {
     EFA_TRY(state_sweeps(c, rows, xm_in, Xp_in, xm_out, Xp_out, ncol));
   }
-  if (c->timing) {
-    EFA_HIP(hipEventRecord(c->ev[3], s));
-    EFA_HIP(hipEventSynchronize(c->ev[3]));
-    float ms = 0.f;
-    EFA_HIP(hipEventElapsedTime(&ms, c->ev[2], c->ev[3]));
-    c->state_ms = ms;
-  }
+  EFA_TRY(finish_state_timing(c, s));
   return EFA_OK;
 }
 
@@ -915,7 +948,12 @@ int efa_ctx_set_option(efa_ctx* c, const char* key, long value) {
     if (value < EFA_PATH_AUTO || value > EFA_PATH_TRANSFORM) return fail(EFA_ERR_INVALID, "path must be 0,1,2");
     c->path = value;
   } else if (!strcmp(key, "timing")) {
-    c->timing = value ? 1 : 0;
+    if (value < 0 || value > 2) return fail(EFA_ERR_INVALID, "timing must be 0, 1 or 2");
+    harvest_obs_ms(c);
+    harvest_state_ms(c);
+    c->timing = value;
+    c->state_ms_sum = c->obs_ms_sum = 0.0;
+    c->state_launches_sum = 0;
   } else if (!strcmp(key, "gram")) {
     if (value < 0 || value > 2) return fail(EFA_ERR_INVALID, "gram must be 0, 1 or 2");
     c->use_gram = value;
@@ -1149,6 +1187,7 @@ int efa_state_cycle_dev(efa_ctx* c, long rows, int M, const double* X_dev, doubl
   EFA_TRY(use(c));
   if (!c->have_traj) return fail(EFA_ERR_INVALID, "efa_state_cycle_dev called before efa_obs_phase_dev");
   if (M != c->M) return fail(EFA_ERR_INVALID, "M=%d differs from the obs phase's M=%d", M, c->M);
+  harvest_state_ms(c);
   c->state_ms = 0.0;
   c->state_launches = 0;
   c->path_taken = EFA_PATH_SWEEP;
@@ -1179,13 +1218,7 @@ int efa_state_cycle_dev(efa_ctx* c, long rows, int M, const double* X_dev, doubl
     EFA_TRY(state_sweeps(c, rows, xm, post_dev, xm, post_dev, ncol));
     EFA_HIP(efa::launch_posterior(rows, M, xm, post_dev, post_dev, s));
   }
-  if (c->timing) {
-    EFA_HIP(hipEventRecord(c->ev[3], s));
-    EFA_HIP(hipEventSynchronize(c->ev[3]));
-    float ms = 0.f;
-    EFA_HIP(hipEventElapsedTime(&ms, c->ev[2], c->ev[3]));
-    c->state_ms = ms;
-  }
+  EFA_TRY(finish_state_timing(c, s));
   return EFA_OK;
 }
 
@@ -1256,14 +1289,19 @@ int efa_cov_contract_f32_dev(efa_ctx* c, long N, int M, long P, const float* Xbp
 
 int efa_last_timing(efa_ctx* c, double* state_ms, double* obs_ms, long* state_launches, int* path_taken) {
   if (!c) return fail(EFA_ERR_INVALID, "null context");
-  if (c->obs_ms_pending) {
-    float ms = 0.f;
-    if (hipEventSynchronize(c->ev[1]) == hipSuccess && hipEventElapsedTime(&ms, c->ev[0], c->ev[1]) == hipSuccess) c->obs_ms = ms;
-    c->obs_ms_pending = false;
+  harvest_obs_ms(c);
+  harvest_state_ms(c);
+  if (c->timing == 2) {  // deferred: the sums over the calls since the previous efa_last_timing
+    if (state_ms) *state_ms = c->state_ms_sum;
+    if (obs_ms) *obs_ms = c->obs_ms_sum;
+    if (state_launches) *state_launches = c->state_launches_sum;
+    c->state_ms_sum = c->obs_ms_sum = 0.0;
+    c->state_launches_sum = 0;
+  } else {
+    if (state_ms) *state_ms = c->state_ms;
+    if (obs_ms) *obs_ms = c->obs_ms;
+    if (state_launches) *state_launches = c->state_launches;
   }
-  if (state_ms) *state_ms = c->state_ms;
-  if (obs_ms) *obs_ms = c->obs_ms;
-  if (state_launches) *state_launches = c->state_launches;
   if (path_taken) *path_taken = c->path_taken;
   return EFA_OK;
 }

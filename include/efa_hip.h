@@ -75,7 +75,7 @@ int efa_ctx_destroy(efa_ctx *ctx);
  * non-blocking stream; efa_ctx_set_option(ctx, "own_stream", 1) returns to it. */
 int efa_ctx_set_stream(efa_ctx *ctx, void *hip_stream);
 /* options: "obs_batch" (obs fused per sweep launch, 1..64, default 64),
- *          "path" (EFA_PATH_*), "timing" (0/1), "pipeline" (1: run Phase A as
+ *          "path" (EFA_PATH_*), "timing" (0/1/2, see efa_last_timing), "pipeline" (1: run Phase A as
  *          one persistent launch when it applies, 0: per-batch kernels),
  *          "gram" (how the persistent launch leads a 64-ob block: 2 (default) in Gram space in
  *          bands of 4 obs, with or without localisation; 1 in Gram space step by step;
@@ -265,7 +265,13 @@ int efa_cov_contract_f32_dev(efa_ctx *ctx, long N, int M, long P,
  * efa_state_phase_dev / efa_state_cycle_dev call, measured with HIP events on
  * the context's stream, plus the number of state-sweep launches and the path
  * taken (EFA_PATH_SWEEP / EFA_PATH_TRANSFORM).  Timing is off by default;
- * enable with efa_ctx_set_option(ctx, "timing", 1). */
+ * enable with efa_ctx_set_option(ctx, "timing", 1): every state-phase call
+ * then ends in a wait for its own end event.  "timing" 2 is the deferred
+ * form for back-to-back cycles: no call waits for its events (an interval is
+ * read when its events are next re-recorded, or here), and efa_last_timing
+ * returns the SUMS of state_ms, obs_ms and state_launches over the calls since
+ * the previous efa_last_timing (which it clears); it waits for the last
+ * recorded events, so call it after the cycles of interest. */
 int efa_last_timing(efa_ctx *ctx, double *state_ms, double *obs_ms,
                     long *state_launches, int *path_taken);
 

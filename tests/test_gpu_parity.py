@@ -1032,3 +1032,46 @@ def test_phase_a_band_leader_random_shapes_vs_oracle():
             for key in ("prior_mean", "prior_var", "post_mean", "post_var"):
                 assert_parity(h_diag[key], diag[key], key)
             assert np.array_equal(h_diag["assimilated"], diag["assimilated"])
+
+
+@pytest.mark.gpu
+def test_deferred_timing_sums_over_back_to_back_cycles():
+    """`timing` 2 (what bench.py runs its timed steps with): no phase call waits for its own events, efa_last_timing returns the
+    sums over the calls since its previous call and clears them; `timing` 1 keeps the per-call meaning.  Results are the same
+    either way."""
+    ctx = _ctx()
+    rng = np.random.default_rng(5)
+    M, P, N = 40, 300, 5000
+    HX = 3.0 * rng.standard_normal((P, M))
+    val = HX.mean(axis=1) + rng.standard_normal(P)
+    err, asm = np.ones(P), np.ones(P, dtype=bool)
+    X = ctx.to_device(rng.standard_normal((N, M)))
+    posts = {}
+    try:
+        for mode in (1, 2):
+            ctx.set_option("timing", mode)
+            post = ctx.empty((N, M))
+            per_call = []
+            for _ in range(3):
+                Yp = ctx.to_device(HX)
+                ym = ctx.empty((P,))
+                ctx.form_perts(P, M, Yp, ym, Yp)
+                ctx.obs_phase(M, P, ym, Yp, val, err, asm)
+                ctx.state_cycle(N, M, X, post)
+                if mode == 1:
+                    per_call.append(ctx.last_timing())
+            ctx.synchronize()
+            t = ctx.last_timing()
+            posts[mode] = post.download()
+            if mode == 1:
+                assert all(c["state_ms"] > 0 and c["obs_ms"] > 0 and c["state_launches"] == 1 for c in per_call)
+                assert t["state_ms"] == per_call[-1]["state_ms"]            # still the last call's
+            else:
+                assert t["state_launches"] == 3 and t["state_ms"] > 0 and t["obs_ms"] > 0
+                again = ctx.last_timing()
+                assert again["state_ms"] == 0.0 and again["obs_ms"] == 0.0 and again["state_launches"] == 0
+        assert np.array_equal(posts[1], posts[2])
+        with pytest.raises(Exception):
+            ctx.set_option("timing", 3)
+    finally:
+        ctx.set_option("timing", 0)
