@@ -74,6 +74,8 @@ def parse_args():
     ap.add_argument("--path", default="auto", choices=["auto", "sweep", "transform"])
     ap.add_argument("--obs-batch", type=int, default=None)
     ap.add_argument("--gram", type=int, default=None, help="Phase-A leader in Gram space (library default if omitted)")
+    ap.add_argument("--split-phases", action="store_true",
+                    help="Phase A and the state phase as two library calls with a host round trip in between (A/B of efa_ensrf_cycle_dev)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-host-api", action="store_true", help="skip the PCIe-inclusive EnSRF.update() timing (N = 1)")
     ap.add_argument("--cpu-rows", type=int, default=0, help="rows of the CPU-baseline sample (0: sized to --cpu-seconds)")
@@ -344,6 +346,8 @@ def main():
     if args.gram is not None:
         ctx.set_option("gram", args.gram)
     ctx.set_option("timing", 2)
+    if args.split_phases:
+        eng.fused_cycle = False
     collective = "none (one rank)"
     if world > 1 and not rehearse:
         collective = init_library_comm(eng, rank, world, dist, torch)

@@ -76,6 +76,12 @@ SIGNATURES = {
     "efa_state_cycle_dev": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_long, ctypes.c_int, ctypes.c_void_p,
                                            ctypes.c_void_p, c_double_p, c_double_p, ctypes.c_long,
                                            ctypes.c_long]),
+    "efa_ensrf_cycle_dev": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_long, ctypes.c_int, ctypes.c_long,
+                                           ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int,
+                                           c_double_p, c_double_p, c_uint8_p, ctypes.c_int,
+                                           c_double_p, c_double_p, c_double_p, c_double_p, c_double_p,
+                                           ctypes.c_long, ctypes.c_long,
+                                           c_double_p, c_double_p, c_double_p, c_double_p, c_uint8_p]),
     "efa_ensrf_update": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_long, ctypes.c_long, ctypes.c_int,
                                         ctypes.c_long, c_double_p, c_double_p,
                                         c_double_p, c_double_p, c_uint8_p, ctypes.c_int,
@@ -398,6 +404,23 @@ class Context(object):
             ncol, n_lead = rows, 1
         _check(self.lib, self.lib.efa_state_cycle_dev(
             self.handle, rows, M, self._addr(X), self._addr(post), _dp(glat), _dp(glon), ncol, n_lead))
+
+    def ensrf_cycle(self, rows, M, P, X, post, ym, Yp, ob_value, ob_error, ob_assim, loc_mode=LOC_NONE,
+                    ob_lat=None, ob_lon=None, ob_halfwidth=None, grid_lat=None, grid_lon=None, n_lead=1, obs_block_out=False):
+        """Phase A + the state phase on resident prior members in ONE call (efa_ensrf_cycle_dev): Phase B goes into the stream
+        behind Phase A without a host round trip when the cycle is unlocalised and takes the transform.  Returns the diagnostics."""
+        val, err, asm, lat, lon, hw = self._ob_arrays(P, ob_value, ob_error, ob_assim, loc_mode,
+                                                      ob_lat, ob_lon, ob_halfwidth)
+        glat, glon, ncol = self._grid(loc_mode, grid_lat, grid_lon)
+        if loc_mode == LOC_NONE:
+            ncol, n_lead = rows, 1
+        d = self._diag_arrays(P)
+        _check(self.lib, self.lib.efa_ensrf_cycle_dev(
+            self.handle, rows, M, P, self._addr(X), self._addr(post), self._addr(ym), self._addr(Yp), 1 if obs_block_out else 0,
+            _dp(val), _dp(err), _u8p(asm), loc_mode, _dp(lat), _dp(lon), _dp(hw), _dp(glat), _dp(glon), ncol, n_lead,
+            _dp(d["prior_mean"]), _dp(d["prior_var"]), _dp(d["post_mean"]), _dp(d["post_var"]), _u8p(d["assimilated"])))
+        d["assimilated"] = d["assimilated"].astype(bool)
+        return d
 
     def ensrf_update_dev(self, rows, M, P, xm, Xp, ym, Yp, ob_value, ob_error, ob_assim,
                          loc_mode=LOC_NONE, ob_lat=None, ob_lon=None, ob_halfwidth=None,

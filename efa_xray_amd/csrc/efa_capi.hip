@@ -146,6 +146,9 @@ struct efa_ctx {
   PinBuf pin_in, pin_out;    // their pinned host images: one H2D and one D2H per call
   PinBuf pin_fs;             // pinned image of the forward-operator stencil
   hipEvent_t ev_fs = nullptr;  // its last host-to-device copy
+  size_t fs_valid_n = 0;       // the device copy fs_idx holds the pinned image's first fs_valid_n stencil entries ...
+  const void* fs_valid_dev = nullptr;  // ... if fs_idx and pin_fs are still these allocations
+  const void* fs_valid_pin = nullptr;
   DevBuf ob_val, ob_err, ob_asm, ob_lat, ob_lon, ob_hw, ob_errsq;  // device copies [P] ([P][4] the last)
   DevBuf d_prior_mean, d_prior_var, d_post_mean, d_post_var, d_assimilated;
   DevBuf Yw, ymw;  // obs block workspace [(P+M)][M], [(P+M)]
@@ -167,10 +170,21 @@ struct efa_ctx {
   int comm_rank = 0, comm_world = 1;
   DevBuf gcc_lat, gcc_lon, gcc_oblat, gcc_oblon, gcc_obhw, gcc_coef, gcc_trig, gcc_cnt, gcc_pairs;  // efa_gc_block_counts
   // --- timing -----------------------------------------------------------------
-  hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
+  hipEvent_t ev[7] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};  // obs phase 0..1; state phase 2..3 and (the fused cycle's second pair) 4..5; 6: Phase A's results on the host (fused cycle)
   double state_ms = 0.0, obs_ms = 0.0;
   bool obs_ms_pending = false;  // ev[0] .. ev[1] of the last obs phase not read yet
-  bool state_ms_pending = false;  // timing 2: ev[2] .. ev[3] of the last state phase not read yet
+  bool state_ms_pending = false;  // ev[2] .. ev[3] of the last state phase not read yet
+  bool state_ms_pending2 = false; // ev[4] .. ev[5] likewise (efa_ensrf_cycle_dev alternates the pairs: it records a state phase's
+                                  // events BEFORE the stream is synchronised, while the previous cycle's may still be unread)
+  // efa_ensrf_cycle_dev: Phase B enqueued behind Phase A before Phase A's status is known
+  struct Spec {
+    bool armed = false, launched = false;
+    const double* X = nullptr;
+    double* post = nullptr;
+    long rows = 0;
+    int pair = 0;  // event pair of the launched transform
+    bool obs_out = true;
+  } spec;
   double state_ms_sum = 0.0, obs_ms_sum = 0.0;  // timing 2: sums since the previous efa_last_timing
   long state_launches_sum = 0;
   long state_launches = 0;
@@ -195,16 +209,22 @@ void harvest_obs_ms(efa_ctx* c) {
   }
   c->obs_ms_pending = false;
 }
-void harvest_state_ms(efa_ctx* c) {
-  if (!c->state_ms_pending) return;
+void harvest_state_pair(efa_ctx* c, int pair) {
+  bool& pending = pair ? c->state_ms_pending2 : c->state_ms_pending;
+  if (!pending) return;
   float ms = 0.f;
-  if (hipEventSynchronize(c->ev[3]) == hipSuccess && hipEventElapsedTime(&ms, c->ev[2], c->ev[3]) == hipSuccess) {
+  if (hipEventSynchronize(c->ev[3 + 2 * pair]) == hipSuccess &&
+      hipEventElapsedTime(&ms, c->ev[2 + 2 * pair], c->ev[3 + 2 * pair]) == hipSuccess) {
     c->state_ms = ms;
     c->state_ms_sum += ms;
   } else {
     (void)hipGetLastError();
   }
-  c->state_ms_pending = false;
+  pending = false;
+}
+void harvest_state_ms(efa_ctx* c) {
+  harvest_state_pair(c, 0);
+  harvest_state_pair(c, 1);
 }
 // end of a state-phase call: timing 1 waits and reads, timing 2 leaves the interval pending
 int finish_state_timing(efa_ctx* c, hipStream_t s) {
@@ -260,6 +280,7 @@ int obs_phase(efa_ctx* c, int M, long P, double* ym_dev, double* Yp_dev, const d
   c->loc_mode = loc_mode;
   c->n_active = 0;
   c->have_transform = false;
+  c->spec.launched = false;
   harvest_obs_ms(c);
   c->obs_ms = 0.0;
   if (P == 0) {
@@ -293,6 +314,7 @@ int obs_phase(efa_ctx* c, int M, long P, double* ym_dev, double* Yp_dev, const d
   const long R = P + extra;
   const size_t dP = (size_t)P * sizeof(double);
 
+  size_t pack_bytes = 0;
   // per-ob inputs: [value | error | assim bytes | {error, sqrt(error), assimilate (1.0 / 0.0), 0} x P | lat | lon | halfwidth] in one
   // allocation, ONE H2D from pinned memory (the last three slots only with localisation); the four-double records are the band
   // leader's per-ob constants, fetched with wave-uniform loads
@@ -328,7 +350,7 @@ int obs_phase(efa_ctx* c, int M, long P, double* ym_dev, double* Yp_dev, const d
     c->ob_lat.carve(db + 7 * slot, slot);
     c->ob_lon.carve(db + 8 * slot, slot);
     c->ob_hw.carve(db + 9 * slot, slot);
-    EFA_HIP(hipMemcpyAsync(db, hb, gc ? total : 7 * slot, hipMemcpyHostToDevice, c->stream));
+    pack_bytes = gc ? total : 7 * slot;  // goes to the device inside the prep launch below (read from the mapped pinned buffer)
   }
   EFA_TRY(c->Ye_rec.reserve((size_t)P * M * sizeof(double)));
   EFA_TRY(c->coef.reserve((size_t)P * kCoefStride * sizeof(double)));
@@ -378,7 +400,8 @@ int obs_phase(efa_ctx* c, int M, long P, double* ym_dev, double* Yp_dev, const d
     EFA_TRY(c->status.reserve(3 * sizeof(int)));
   }
   EFA_HIP(launch_phase_a_prep(P, M, Yp_dev, ym_dev, Yw, ymw, carry_T ? 1 : 0, pipe_ok ? c->traj.as<unsigned long long>() : nullptr,
-                              pipe_ok ? (size_t)P * TS : 0, kTrajSentinel, pipe_ok ? c->status.as<int>() : nullptr, s));
+                              pipe_ok ? (size_t)P * TS : 0, kTrajSentinel, pipe_ok ? c->status.as<int>() : nullptr,
+                              c->pin_in.p, c->ob_pack.p, pack_bytes, s));
   bool status_clear = pipe_ok;  // (cleared by the prep launch: the first window's launch needs no memset of its own)
   // rows [lo, hi) of the obs block take obs [b0, b0 + nb) from (Ye, ye_stride): the per-batch sweep
   auto sweep_rows = [&](long b0, int nb, const double* Ye, long ye_stride, long skip_lo, long skip_hi, long nrows) -> int {
@@ -530,15 +553,46 @@ int obs_phase(efa_ctx* c, int M, long P, double* ym_dev, double* Yp_dev, const d
         // it wrote come back together, into pinned memory (a second copy + synchronise after the status was known left the
         // device idle for ~40 us before Phase B; a pageable destination made the status copy itself a staged one)
         int* st = reinterpret_cast<int*>(static_cast<char*>(c->pin_out.p) + 5 * oslot - 64);
-        EFA_HIP(hipMemcpyAsync(st, c->status.p, 3 * sizeof(int), hipMemcpyDeviceToHost, s));
-        if (direct) EFA_HIP(hipMemcpyAsync(c->pin_out.p, c->out_pack.p, 4 * oslot + (size_t)P, hipMemcpyDeviceToHost, s));
-        EFA_HIP(hipStreamSynchronize(s));
+        if (direct) EFA_HIP(launch_results_to_host(c->out_pack.p, c->pin_out.p, 4 * oslot + (size_t)P, c->status.as<int>(), st, s));
+        else EFA_HIP(hipMemcpyAsync(st, c->status.p, 3 * sizeof(int), hipMemcpyDeviceToHost, s));
+        // efa_ensrf_cycle_dev: the state transform goes into the stream HERE, behind the launch whose status is not known
+        // yet -- it reads [T | w] from the launch's working rows and writes only the caller's posterior; a launch that
+        // reports a fallback is redone below and the transform enqueued again (by the caller), so a wrong guess costs time, never
+        // a result.  The device then runs Phase A -> Phase B with no host round trip in between.
+        bool spec_now = false;
+        if (c->spec.armed && c->spec.rows > 0 && direct && carry_T && c->n_active > 0 &&
+            (c->path == EFA_PATH_TRANSFORM || (c->path == EFA_PATH_AUTO && c->n_active > M / 2))) {
+          const int pr = c->state_ms_pending ? 1 : 0;
+          EFA_HIP(hipEventRecord(c->ev[6], s));  // the status words and diagnostics are on the host: what the host waits for below
+          if (c->timing) {
+            harvest_state_pair(c, pr);  // (both pairs unread cannot happen across the synchronisation below; kept correct anyway)
+            EFA_HIP(hipEventRecord(c->ev[1], s));
+            EFA_HIP(hipEventRecord(c->ev[2 + 2 * pr], s));
+          }
+          TransformArgs t{};
+          t.Xin = c->spec.X;
+          t.Xout = c->spec.post;
+          t.nrows = c->spec.rows;
+          t.M = M;
+          t.T = Yw + (size_t)P * M;
+          t.w = ymw + P;
+          t.fused_members = 1;
+          EFA_HIP(launch_transform(t, s));
+          if (c->timing) EFA_HIP(hipEventRecord(c->ev[3 + 2 * pr], s));
+          c->spec.pair = pr;
+          spec_now = true;
+        }
+        if (spec_now) EFA_HIP(hipEventSynchronize(c->ev[6]));  // (not the stream: the transform behind it is to run while the host goes on)
+        else EFA_HIP(hipStreamSynchronize(s));
+        c->spec.launched = false;
+        if (spec_now && c->timing) harvest_state_pair(c, 1 - c->spec.pair);  // the previous cycle's interval: complete by now
         if (st[0] == 0 && st[1] == 0) {
           done = true;
           any_pipeline = true;
           traj_kind_band = (kind == 4);
           c->phase_a_kind = kind;
           diag_on_host = direct;
+          c->spec.launched = spec_now;
         } else {
           if (direct) {
             EFA_HIP(hipMemcpyAsync(Yw, Yp_dev, (size_t)P * M * sizeof(double), hipMemcpyDeviceToDevice, s));
@@ -618,9 +672,11 @@ int obs_phase(efa_ctx* c, int M, long P, double* ym_dev, double* Yp_dev, const d
     c->ye_ptr = reinterpret_cast<const double*>(c->traj.p);
     c->ye_stride = traj_kind_band ? TS_band : TS_std;
   }
-  EFA_HIP(hipMemcpyAsync(Yp_dev, Yw, (size_t)P * M * sizeof(double), hipMemcpyDeviceToDevice, s));
-  EFA_HIP(hipMemcpyAsync(ym_dev, ymw, dP, hipMemcpyDeviceToDevice, s));
-  if (c->timing) EFA_HIP(hipEventRecord(c->ev[1], s));
+  if (!c->spec.armed || c->spec.obs_out) {
+    EFA_HIP(hipMemcpyAsync(Yp_dev, Yw, (size_t)P * M * sizeof(double), hipMemcpyDeviceToDevice, s));
+    EFA_HIP(hipMemcpyAsync(ym_dev, ymw, dP, hipMemcpyDeviceToDevice, s));
+  }
+  if (c->timing && !c->spec.launched) EFA_HIP(hipEventRecord(c->ev[1], s));  // (a speculative transform: recorded in front of it)
 
   // diagnostics back to the caller (ensrf.py:66,70,75,146-149)
   if (!diag_on_host) {
@@ -894,7 +950,7 @@ int efa_ctx_create(int device_id, efa_ctx** out) {
     return fail(EFA_ERR_HIP, "hipStreamCreate failed: %s", hipGetErrorString(es));
   }
   c->stream = c->own_stream;
-  for (int i = 0; i < 4; ++i) {
+  for (int i = 0; i < 7; ++i) {
     hipError_t ee = hipEventCreate(&c->ev[i]);
     if (ee != hipSuccess) {
       efa_ctx_destroy(c);
@@ -920,7 +976,7 @@ int efa_ctx_destroy(efa_ctx* c) {
                     &c->Yw, &c->ymw, &c->win_Y, &c->win_m, &c->traj, &c->tw_mat, &c->status, &c->dbg, &c->W, &c->gc_cnt, &c->gc_ub, &c->gc_order, &c->gc_obtrig, &c->gc_off, &c->gc_idx, &c->gc_wts, &c->gc_pairs, &c->glat, &c->glon, &c->xm_ws, &c->fs_idx, &c->fs_wts, &c->f_glat, &c->f_glon, &c->f_sl, &c->f_cl, &c->f_valids, &c->f_var, &c->f_time, &c->f_lat, &c->f_lon, &c->f_near, &c->f_idx, &c->f_wts, &c->f_status, &c->h_xm, &c->h_Xp, &c->h_ym, &c->h_Yp,
                     &c->gcc_lat, &c->gcc_lon, &c->gcc_oblat, &c->gcc_oblon, &c->gcc_obhw, &c->gcc_coef, &c->gcc_trig, &c->gcc_cnt, &c->gcc_pairs};
   for (DevBuf* b : bufs) b->release();
-  for (int i = 0; i < 4; ++i)
+  for (int i = 0; i < 7; ++i)
     if (c->ev[i]) (void)hipEventDestroy(c->ev[i]);
   if (c->dbg_stream) {
     (void)hipStreamSynchronize(c->dbg_stream);
@@ -1084,10 +1140,21 @@ int efa_forward_stencil_dev(efa_ctx* c, long rows, long row_offset, int M, const
   EFA_TRY(c->pin_fs.reserve(2 * half));
   if (!c->ev_fs) EFA_HIP(hipEventCreateWithFlags(&c->ev_fs, hipEventDisableTiming));
   else EFA_HIP(hipEventSynchronize(c->ev_fs));
-  std::memcpy(c->pin_fs.p, idx, n * sizeof(int64_t));
-  std::memcpy(static_cast<char*>(c->pin_fs.p) + half, wts, n * sizeof(double));
-  EFA_HIP(hipMemcpyAsync(c->fs_idx.p, c->pin_fs.p, half + n * sizeof(double), hipMemcpyHostToDevice, c->stream));
-  EFA_HIP(hipEventRecord(c->ev_fs, c->stream));
+  // A fixed observing network hands over the same stencil cycle after cycle: when the pinned image still holds exactly these
+  // indices and weights, the device copy made from it is current and nothing is copied (the copy itself is 8 us at 1e4 obs, but
+  // a copy between two kernels idles the stream for ~10 us on either side).
+  char* pin = static_cast<char*>(c->pin_fs.p);
+  const bool same = c->fs_valid_n == n && c->fs_valid_dev == c->fs_idx.p && c->fs_valid_pin == c->pin_fs.p && std::memcmp(pin, idx, n * sizeof(int64_t)) == 0 &&
+                    std::memcmp(pin + half, wts, n * sizeof(double)) == 0;
+  if (!same) {
+    std::memcpy(pin, idx, n * sizeof(int64_t));
+    std::memcpy(pin + half, wts, n * sizeof(double));
+    EFA_HIP(hipMemcpyAsync(c->fs_idx.p, c->pin_fs.p, half + n * sizeof(double), hipMemcpyHostToDevice, c->stream));
+    EFA_HIP(hipEventRecord(c->ev_fs, c->stream));
+    c->fs_valid_n = n;
+    c->fs_valid_dev = c->fs_idx.p;
+    c->fs_valid_pin = c->pin_fs.p;
+  }
   EFA_HIP(efa::launch_forward_stencil(rows, row_offset, M, X_dev, P, npt, c->fs_idx.as<int64_t>(),
                                       reinterpret_cast<const double*>(static_cast<const char*>(c->fs_idx.p) + half), HX_dev,
                                       c->stream));
@@ -1233,6 +1300,46 @@ int efa_ensrf_update_dev(efa_ctx* c, long rows, int M, long P, double* xm_dev, d
   EFA_TRY(state_phase(c, rows, M, xm_dev, Xp_dev, xm_dev, Xp_dev, grid_lat, grid_lon, ncol, n_lead));
   EFA_HIP(hipStreamSynchronize(c->stream));
   return EFA_OK;
+}
+
+int efa_ensrf_cycle_dev(efa_ctx* c, long rows, int M, long P, const double* X_dev, double* post_dev, double* ym_dev,
+                        double* Yp_dev, int obs_block_out, const double* ob_value, const double* ob_error,
+                        const uint8_t* ob_assim, int loc_mode, const double* ob_lat, const double* ob_lon,
+                        const double* ob_halfwidth_km, const double* grid_lat, const double* grid_lon, long ncol, long n_lead,
+                        double* prior_mean, double* prior_var, double* post_mean, double* post_var, uint8_t* assimilated) {
+  EFA_TRY(use(c));
+  if (rows < 0) return fail(EFA_ERR_INVALID, "negative row count");
+  if (rows > 0 && (!X_dev || !post_dev)) return fail(EFA_ERR_INVALID, "null state pointer");
+  // Phase B may go into the stream before Phase A's status is known only if a wrong guess cannot cost the prior:
+  // separate prior and posterior buffers (a redone Phase A needs the transform run again on the untouched prior)
+  const char* xb = reinterpret_cast<const char*>(X_dev);
+  const char* pb = reinterpret_cast<const char*>(post_dev);
+  const size_t bytes = (size_t)rows * (size_t)(M > 0 ? M : 0) * sizeof(double);
+  const bool disjoint = rows > 0 && (xb + bytes <= pb || pb + bytes <= xb);
+  c->spec = efa_ctx::Spec{};
+  c->spec.armed = true;
+  c->spec.obs_out = obs_block_out != 0;
+  c->spec.X = X_dev;
+  c->spec.post = post_dev;
+  c->spec.rows = (disjoint && loc_mode == EFA_LOC_NONE) ? rows : 0;  // 0: armed only for the optional obs-block copy
+  const int rc = obs_phase(c, M, P, ym_dev, Yp_dev, ob_value, ob_error, ob_assim, loc_mode, ob_lat, ob_lon, ob_halfwidth_km,
+                           prior_mean, prior_var, post_mean, post_var, assimilated);
+  const bool launched = c->spec.launched;
+  const int pair = c->spec.pair;
+  c->spec = efa_ctx::Spec{};
+  if (rc != EFA_OK) return rc;
+  if (launched) {  // Phase B is in the stream already, behind the launch that turned out fine
+    c->state_ms = 0.0;
+    c->state_launches = 1;
+    c->state_launches_sum += 1;
+    c->path_taken = EFA_PATH_TRANSFORM;
+    if (c->timing) {
+      (pair ? c->state_ms_pending2 : c->state_ms_pending) = true;
+      if (c->timing == 1) harvest_state_pair(c, pair);
+    }
+    return EFA_OK;
+  }
+  return efa_state_cycle_dev(c, rows, M, X_dev, post_dev, grid_lat, grid_lon, ncol, n_lead);
 }
 
 int efa_ensrf_update(efa_ctx* c, long A, long N, int M, long P, double* xbm, double* Xbp, const double* ob_value,

@@ -208,7 +208,9 @@ hipError_t launch_fill_synthetic(long rows, long row_offset, int M, uint64_t see
                                  double* X, hipStream_t s);
 hipError_t launch_set_identity(int M, double* T, double* w, hipStream_t s);
 hipError_t launch_phase_a_prep(long P, int M, const double* Yp, const double* ym, double* Yw, double* ymw, int carry_T,
-                               unsigned long long* traj, size_t traj_words, unsigned long long sentinel, int* status, hipStream_t s);
+                               unsigned long long* traj, size_t traj_words, unsigned long long sentinel, int* status,
+                               const void* pack_host, void* pack_dev, size_t pack_bytes, hipStream_t s);
+hipError_t launch_results_to_host(const void* src_dev, void* dst_host, size_t bytes, const int* st_dev, int* st_host, hipStream_t s);
 // diagnostic: `blocks` workgroups that hold `lds_bytes` of LDS each and spin for `ms` milliseconds
 hipError_t launch_occupy(int blocks, size_t lds_bytes, double ms, hipStream_t s);
 hipError_t launch_contract_f32(long N, int M, long P, const float* X, const float* Ye, float* C, hipStream_t s);

@@ -189,10 +189,15 @@ hipError_t launch_occupy(int blocks, size_t lds_bytes, double ms, hipStream_t s)
 // Everything one Phase-A call needs before its first launch, in ONE launch (five small operations cost ~10 us of launch
 // latency each -- a fifth of configs[1]'s whole cycle): the caller's obs block into the working rows, the identity rows
 // that come out as [T|w], the trajectory records filled with their sentinel, the status words cleared.
+// (Round 3, late: the per-ob input pack also comes in HERE, read by the kernel straight from the mapped pinned buffer the host
+//  filled -- 16 bytes per thread, each read once.  As a copy of its own it sat between two kernels on the copy engine, and every
+//  kernel <-> copy switch leaves the stream idle for ~10 us: 15 us of copy + 20 us of gaps per cycle.)
 __global__ void k_phase_a_prep(long P, int M, const double* __restrict__ Yp, const double* __restrict__ ym, double* __restrict__ Yw,
                                double* __restrict__ ymw, int carry_T, unsigned long long* __restrict__ traj, size_t traj_words,
-                               unsigned long long sentinel, int* __restrict__ status) {
+                               unsigned long long sentinel, int* __restrict__ status, const uint4* __restrict__ pack_host,
+                               uint4* __restrict__ pack_dev, size_t pack_n16) {
   const size_t tid = (size_t)blockIdx.x * blockDim.x + threadIdx.x, nth = (size_t)gridDim.x * blockDim.x;
+  for (size_t i = tid; i < pack_n16; i += nth) pack_dev[i] = pack_host[i];
   const size_t n = (size_t)P * M;
   if ((n & 1) == 0 && ((reinterpret_cast<uintptr_t>(Yp) | reinterpret_cast<uintptr_t>(Yw)) & 15u) == 0) {
     const double2* src = reinterpret_cast<const double2*>(Yp);
@@ -213,11 +218,28 @@ __global__ void k_phase_a_prep(long P, int M, const double* __restrict__ Yp, con
 }
 
 hipError_t launch_phase_a_prep(long P, int M, const double* Yp, const double* ym, double* Yw, double* ymw, int carry_T,
-                               unsigned long long* traj, size_t traj_words, unsigned long long sentinel, int* status, hipStream_t s) {
+                               unsigned long long* traj, size_t traj_words, unsigned long long sentinel, int* status,
+                               const void* pack_host, void* pack_dev, size_t pack_bytes, hipStream_t s) {
   size_t work = (size_t)P * M / 2 + 1;
   if (traj && traj_words > work) work = traj_words;
   hipLaunchKernelGGL(k_phase_a_prep, dim3(grid_for(work, 256 * 4)), dim3(256), 0, s, P, M, Yp, ym, Yw, ymw, carry_T, traj, traj_words,
-                     sentinel, status);
+                     sentinel, status, static_cast<const uint4*>(pack_host), static_cast<uint4*>(pack_dev), pack_bytes / 16);
+  return hipGetLastError();
+}
+
+// A persistent Phase-A launch's status words and the diagnostics it wrote, stored by a kernel straight into mapped pinned host
+// memory (coalesced 16-byte stores, each byte once): behind it the next kernel starts at once, where two device-to-host copies
+// cost 15 us plus a ~10 us engine switch on either side.  The host reads them after waiting for an event recorded behind this kernel.
+__global__ void k_results_to_host(const uint4* __restrict__ src, uint4* __restrict__ dst, size_t n16, const int* __restrict__ st_src,
+                                  int* __restrict__ st_dst) {
+  const size_t tid = (size_t)blockIdx.x * blockDim.x + threadIdx.x, nth = (size_t)gridDim.x * blockDim.x;
+  for (size_t i = tid; i < n16; i += nth) dst[i] = src[i];
+  if (tid < 3) st_dst[tid] = st_src[tid];
+}
+hipError_t launch_results_to_host(const void* src_dev, void* dst_host, size_t bytes, const int* st_dev, int* st_host, hipStream_t s) {
+  const size_t n16 = (bytes + 15) / 16;
+  hipLaunchKernelGGL(k_results_to_host, dim3(grid_for(n16 ? n16 : 1, 256)), dim3(256), 0, s, static_cast<const uint4*>(src_dev),
+                     static_cast<uint4*>(dst_host), n16, st_dev, st_host);
   return hipGetLastError();
 }
 

@@ -101,6 +101,7 @@ class HipEngine(object):
         self.ctx = _lib.Context(device)
         self.ctx.set_stream(torch.cuda.current_stream().cuda_stream)
         self.has_comm = False
+        self.fused_cycle = True     # ShardedEnSRF.assimilate: Phase A + state phase as one library call (efa_ensrf_cycle_dev)
 
     def init_comm(self, rank, world_size, group=None):
         """Create the library-owned RCCL communicator.  Collective over `group` (torch.distributed, any
@@ -143,6 +144,14 @@ class HipEngine(object):
 
     def state_cycle(self, rows, M, X, post, grid_lat, grid_lon, n_lead):
         self.ctx.state_cycle(rows, M, X.data_ptr(), post.data_ptr(), grid_lat, grid_lon, n_lead)
+
+    def cycle(self, rows, M, P, X, post, ym, Yp, ob, grid_lat, grid_lon, n_lead):
+        """obs_phase + state_cycle as ONE library call (efa_ensrf_cycle_dev): no host round trip between Phase A and Phase B
+        when the transform applies; the augmented obs rows are not copied back (the reference discards them)."""
+        return self.ctx.ensrf_cycle(rows, M, P, X.data_ptr(), post.data_ptr(), ym.data_ptr(), Yp.data_ptr(),
+                                    ob["value"], ob["error"], ob["assim"],
+                                    _lib.LOC_GC if ob.get("loc") == "GC" else _lib.LOC_NONE,
+                                    ob.get("lat"), ob.get("lon"), ob.get("halfwidth"), grid_lat, grid_lon, n_lead)
 
 
 class ShardedEnSRF(object):
@@ -219,11 +228,13 @@ class ShardedEnSRF(object):
         P = int(HX.shape[0])
         ym = eng.empty((max(P, 1),))
         eng.form_perts(P, M, HX, ym, HX)                                   # assimilation.py:46-48
-        diag = eng.obs_phase(M, P, ym, HX, ob)                             # identical on every rank
         glat = glon = None
         if ob.get("loc") == "GC":
             glat = np.ascontiguousarray(np.asarray(grid_lat, dtype=np.float64).reshape(-1)[self.lo:self.hi])
             glon = np.ascontiguousarray(np.asarray(grid_lon, dtype=np.float64).reshape(-1)[self.lo:self.hi])
+        if getattr(eng, "fused_cycle", False):                             # one library call for both phases
+            return eng.cycle(self.rows_local, M, P, X_local, post_local, ym, HX, ob, glat, glon, self.n_lead)
+        diag = eng.obs_phase(M, P, ym, HX, ob)                             # identical on every rank
         eng.state_cycle(self.rows_local, M, X_local, post_local, glat, glon, self.n_lead)
         return diag
 

@@ -234,6 +234,32 @@ int efa_state_cycle_dev(efa_ctx *ctx, long rows, int M, const double *X_dev,
                         double *post_dev, const double *grid_lat,
                         const double *grid_lon, long ncol, long n_lead);
 
+/* ---- one whole cycle on resident prior members, ONE call ------------------
+ * efa_obs_phase_dev followed by efa_state_cycle_dev (ensrf.py:50-149 on the obs
+ * block, then on every state row; same arguments, same results bit for bit),
+ * with one difference in how the device is driven: when the cycle is
+ * unlocalised, takes the transform path, fits one persistent Phase-A launch and
+ * X_dev / post_dev do not overlap, the state transform is put into the stream
+ * BEHIND the Phase-A launch before the host has seen that launch's status, so
+ * the device goes from Phase A to Phase B without a host round trip.  A launch
+ * that then reports a fallback (bounded spin expired, cancellation guard) is
+ * redone by the other Phase-A kernels and the transform enqueued again: a
+ * wrong guess costs one wasted pass, never a result (the prior is only read).
+ * obs_block_out 0 leaves ym_dev / Yp_dev as they came (the reference discards
+ * the augmented obs rows: format_posterior_state keeps [:N], assimilation.py:168);
+ * 1 returns the final obs block in them like efa_obs_phase_dev. */
+int efa_ensrf_cycle_dev(efa_ctx *ctx, long rows, int M, long P,
+                        const double *X_dev, double *post_dev, double *ym_dev,
+                        double *Yp_dev, int obs_block_out,
+                        const double *ob_value, const double *ob_error,
+                        const uint8_t *ob_assim, int loc_mode,
+                        const double *ob_lat, const double *ob_lon,
+                        const double *ob_halfwidth_km, const double *grid_lat,
+                        const double *grid_lon, long ncol, long n_lead,
+                        double *prior_mean, double *prior_var,
+                        double *post_mean, double *post_var,
+                        uint8_t *assimilated);
+
 /* ---- host-memory convenience: the augmented arrays of the reference ------
  * xbm[A], Xbp[A*M] (A = N + P) exactly as format_prior_state returns them
  * (assimilation.py:154), updated in place to the (xam, Xap) handed to
@@ -262,7 +288,7 @@ int efa_cov_contract_f32_dev(efa_ctx *ctx, long N, int M, long P,
 /* ---- measurement support --------------------------------------------------
  * Device time (ms) spent in the state-sweep kernels and in the obs-space
  * kernels during the most recent efa_ensrf_update_dev / efa_obs_phase_dev /
- * efa_state_phase_dev / efa_state_cycle_dev call, measured with HIP events on
+ * efa_state_phase_dev / efa_state_cycle_dev / efa_ensrf_cycle_dev call, measured with HIP events on
  * the context's stream, plus the number of state-sweep launches and the path
  * taken (EFA_PATH_SWEEP / EFA_PATH_TRANSFORM).  Timing is off by default;
  * enable with efa_ctx_set_option(ctx, "timing", 1): every state-phase call

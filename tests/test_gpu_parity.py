@@ -1075,3 +1075,120 @@ def test_deferred_timing_sums_over_back_to_back_cycles():
             ctx.set_option("timing", 3)
     finally:
         ctx.set_option("timing", 0)
+
+
+def _cycle_two_ways(c, fused_kwargs=None, path="auto"):
+    """The same resident cycle through efa_obs_phase_dev + efa_state_cycle_dev and through efa_ensrf_cycle_dev."""
+    ctx = _ctx()
+    ctx.set_option("path", {"auto": 0, "sweep": 1, "transform": 2}[path])
+    N, M, P = c["N"], c["M"], c["P"]
+    loc = 1 if c["loc"] else 0
+    okw = dict(loc_mode=loc)
+    gl = gn = None
+    n_lead = 1
+    if loc:
+        okw.update(ob_lat=c["ob_lat"], ob_lon=c["ob_lon"], ob_halfwidth=c["hw"])
+        gl, gn, n_lead = c["lat"].reshape(-1), c["lon"].reshape(-1), c["n_lead"]
+    out = {}
+    try:
+        for how in ("split", "fused"):
+            X = ctx.to_device(c["X"])
+            post = ctx.empty((N, M))
+            Yp = ctx.to_device(c["HX"])
+            ym = ctx.empty((P,))
+            ctx.form_perts(P, M, Yp, ym, Yp)
+            if how == "split":
+                d = ctx.obs_phase(M, P, ym, Yp, c["val"], c["err"], c["asm"], **okw)
+                ctx.state_cycle(N, M, X, post, gl, gn, n_lead)
+            else:
+                d = ctx.ensrf_cycle(N, M, P, X, post, ym, Yp, c["val"], c["err"], c["asm"], grid_lat=gl, grid_lon=gn, n_lead=n_lead,
+                                    **dict(okw, **(fused_kwargs or {})))
+            out[how] = (post.download(), Yp.download(), ym.download(), d, ctx.get_option("phase_a_kind"), ctx.last_timing()["path"])
+    finally:
+        ctx.set_option("path", 0)
+    return out
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("loc", [False, True])
+def test_fused_cycle_equals_obs_phase_plus_state_cycle(loc):
+    """efa_ensrf_cycle_dev == efa_obs_phase_dev + efa_state_cycle_dev bit for bit -- unlocalised (Phase B enqueued behind
+    Phase A before its status is known), localised (no speculation) -- and against the oracle; obs_block_out."""
+    c = _random_case(4242, 2048 if loc else 3000, 50, 500, loc, frac_assim=0.9, ncol=(512 if loc else None))
+    xam, Xap, diag = _run_oracle(c)
+    ref_post = orc.format_posterior_state(xam, Xap, c["N"])
+    ym0, Yp0 = orc.compute_ob_priors(c["HX"])
+    for obs_out in (False, True):
+        r = _cycle_two_ways(c, dict(obs_block_out=obs_out))
+        s, f = r["split"], r["fused"]
+        assert np.array_equal(f[0], s[0]), "posterior members"
+        assert_parity(f[0], ref_post, "post vs oracle")
+        for key in ("prior_mean", "prior_var", "post_mean", "post_var"):
+            assert np.array_equal(f[3][key], s[3][key], equal_nan=True), key
+            assert_parity(f[3][key], diag[key], key)
+        assert np.array_equal(f[3]["assimilated"], s[3]["assimilated"])
+        assert f[4] == s[4] == 4 and f[5] == s[5] == (1 if loc else 2)
+        if obs_out:      # the final obs block comes back as from efa_obs_phase_dev
+            assert np.array_equal(f[1], s[1]) and np.array_equal(f[2], s[2])
+        else:            # the caller's obs priors are left alone
+            assert_parity(f[1], Yp0, "obs perturbations untouched")
+            assert_parity(f[2], ym0, "obs means untouched")
+
+
+@pytest.mark.gpu
+def test_fused_cycle_when_the_speculated_launch_falls_back():
+    """The Gram-space cancellation guard trips in the launch behind which Phase B was enqueued: Phase A is redone by the
+    vector-chain kernel and Phase B enqueued again -- the wasted transform must leave no trace."""
+    c = _random_case(77, 3000, 24, 90, False, frac_assim=1.0)
+    c["HX"][1:40] = c["HX"][0] + 1e-4 * np.random.default_rng(3).standard_normal((39, 24))
+    c["val"][:40] = c["HX"][0].mean() + 0.1
+    c["err"][:40] = 1e-8
+    xam, Xap, diag = _run_oracle(c)
+    r = _cycle_two_ways(c, path="transform")
+    s, f = r["split"], r["fused"]
+    assert f[4] == s[4] == 1, "the guard must have handed Phase A to the vector-chain kernel"
+    assert np.array_equal(f[0], s[0])
+    assert_parity(f[0], orc.format_posterior_state(xam, Xap, c["N"]), "post vs oracle")
+    assert_parity(f[3]["post_var"], diag["post_var"], "post_var")
+
+
+@pytest.mark.gpu
+def test_fused_cycle_in_place_and_edge_cases():
+    """post_dev == X_dev (no speculation: a wrong guess would cost the prior), no obs, none assimilated, deferred timing."""
+    ctx = _ctx()
+    c = _random_case(99, 1000, 40, 200, False, frac_assim=0.9)
+    xam, Xap, _ = _run_oracle(c)
+    ref_post = orc.format_posterior_state(xam, Xap, c["N"])
+    N, M, P = c["N"], c["M"], c["P"]
+    X = ctx.to_device(c["X"])
+    Yp = ctx.to_device(c["HX"])
+    ym = ctx.empty((P,))
+    ctx.form_perts(P, M, Yp, ym, Yp)
+    ctx.ensrf_cycle(N, M, P, X, X, ym, Yp, c["val"], c["err"], c["asm"])
+    assert_parity(X.download(), ref_post, "in-place cycle")
+    # none assimilated / no obs: the posterior is the prior
+    for Pz, asm in ((P, np.zeros(P, dtype=bool)), (0, np.zeros(0, dtype=bool))):
+        X = ctx.to_device(c["X"])
+        post = ctx.empty((N, M))
+        Yp = ctx.to_device(c["HX"][:max(Pz, 1)])
+        ym = ctx.empty((max(Pz, 1),))
+        ctx.form_perts(max(Pz, 1), M, Yp, ym, Yp)
+        d = ctx.ensrf_cycle(N, M, Pz, X, post, ym, Yp, c["val"][:Pz], c["err"][:Pz], asm)
+        assert_parity(post.download(), c["X"], "no update")
+        assert not d["assimilated"].any()
+    # deferred timing across fused cycles: sums, one transform launch per cycle, and the host is not held by the events
+    try:
+        ctx.set_option("timing", 2)
+        X = ctx.to_device(c["X"])
+        post = ctx.empty((N, M))
+        ym = ctx.empty((P,))
+        for _ in range(4):
+            Yp = ctx.to_device(c["HX"])
+            ctx.form_perts(P, M, Yp, ym, Yp)
+            ctx.ensrf_cycle(N, M, P, X, post, ym, Yp, c["val"], c["err"], c["asm"])
+        ctx.synchronize()
+        t = ctx.last_timing()
+        assert t["state_launches"] == 4 and t["state_ms"] > 0 and t["obs_ms"] > 0 and t["path"] == 2
+        assert_parity(post.download(), ref_post, "post after four cycles")
+    finally:
+        ctx.set_option("timing", 0)
