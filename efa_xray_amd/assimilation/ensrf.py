@@ -116,8 +116,9 @@ class EnSRF(Assimilation):
 
         if self.verbose:
             print("Beginning observation loop")
-        diag = ctx.obs_phase(M, P, ym, Yp, value, error, assim, loc_mode, lat, lon, hw)
-        ctx.state_cycle(N, M, X, X, grid_lat, grid_lon, n_lead)
+        # Phase A (ensrf.py:50-149 on the obs block) and the state phase in one library call; in place, so nothing is
+        # enqueued ahead of Phase A's status (efa_ensrf_cycle_dev speculates only into a separate posterior buffer)
+        diag = ctx.ensrf_cycle(N, M, P, X, X, ym, Yp, value, error, assim, loc_mode, lat, lon, hw, grid_lat, grid_lon, n_lead)
         self.last_timing = ctx.last_timing()
 
         # diagnostics onto the observations, as ensrf.py:66,70,75,146-149
