@@ -157,6 +157,11 @@ struct efa_ctx {
   DevBuf W;           // taper table [nb][ncol]
   DevBuf gc_cnt, gc_ub, gc_order, gc_obtrig, gc_off, gc_idx, gc_wts, gc_pairs;  // one-pass GC sweep: CSR active lists
   long gc_active_pairs = 0;  // (column, ob) pairs with a non-zero taper in the last one-pass sweep
+  bool gc_pairs_pending = false;  // ... still on the device (read when asked for, or before the counter is cleared again: a read
+                                  // behind the sweep would hold the host until the sweep is done, cycle after cycle)
+  PinBuf pin_grid;           // pinned mirror of the column lat/lon on the device (glat | glon)
+  long grid_ncol = -1;       // columns the mirror and the device copies hold (-1: none)
+  bool grid_ready = false;   // efa_ensrf_cycle_dev brought the grid up to date ahead of Phase A: the state phase must not again
   DevBuf glat, glon;  // grid lat/lon [ncol]
   DevBuf xm_ws;       // means for efa_state_cycle_dev
   // --- f1: interpolation stencils -------------------------------------------------
@@ -716,9 +721,54 @@ int prepare_grid(efa_ctx* c, const double* grid_lat, const double* grid_lon, lon
   if (!grid_lat || !grid_lon) return fail(EFA_ERR_INVALID, "GC localisation needs grid_lat/grid_lon");
   if (ncol <= 0 || n_lead <= 0 || ncol * n_lead != rows)
     return fail(EFA_ERR_INVALID, "rows=%ld must equal n_lead*ncol = %ld*%ld", rows, n_lead, ncol);
+  if (c->grid_ready) {  // (the fused cycle did this before Phase A, while the device was still busy with the previous cycle)
+    c->grid_ready = false;
+    return EFA_OK;
+  }
   EFA_TRY(h2d(c, c->glat, grid_lat, (size_t)ncol * sizeof(double)));
   EFA_TRY(h2d(c, c->glon, grid_lon, (size_t)ncol * sizeof(double)));
+  c->grid_ncol = -1;
   EFA_HIP(hipStreamSynchronize(c->stream));  // caller may reuse grid_lat/grid_lon on return
+  return EFA_OK;
+}
+
+// The same grid ahead of Phase A (efa_ensrf_cycle_dev): compared with a pinned mirror of what the device holds and copied -- from
+// the mirror, asynchronously -- only if it differs.  Cycle after cycle on one grid nothing is copied; the comparison (4 MB at
+// configs[3]) is host time spent while the device still works on the previous cycle.
+int prepare_grid_early(efa_ctx* c, int loc_mode, const double* grid_lat, const double* grid_lon, long ncol, long n_lead, long rows) {
+  c->grid_ready = false;
+  if (loc_mode != EFA_LOC_GC || rows <= 0) return EFA_OK;
+  if (!grid_lat || !grid_lon) return fail(EFA_ERR_INVALID, "GC localisation needs grid_lat/grid_lon");
+  if (ncol <= 0 || n_lead <= 0 || ncol * n_lead != rows)
+    return fail(EFA_ERR_INVALID, "rows=%ld must equal n_lead*ncol = %ld*%ld", rows, n_lead, ncol);
+  const size_t nb = (size_t)ncol * sizeof(double);
+  const void* pin_before = c->pin_grid.p;
+  EFA_TRY(c->pin_grid.reserve(2 * nb));
+  char* pin = static_cast<char*>(c->pin_grid.p);
+  const void *dl = c->glat.p, *dn = c->glon.p;
+  EFA_TRY(c->glat.reserve(nb));
+  EFA_TRY(c->glon.reserve(nb));
+  const bool same = c->grid_ncol == ncol && pin_before == c->pin_grid.p && dl == c->glat.p && dn == c->glon.p &&
+                    std::memcmp(pin, grid_lat, nb) == 0 && std::memcmp(pin + nb, grid_lon, nb) == 0;
+  if (!same) {
+    EFA_HIP(hipStreamSynchronize(c->stream));  // (an earlier copy out of the mirror may be in flight; a new grid is the rare case)
+    std::memcpy(pin, grid_lat, nb);
+    std::memcpy(pin + nb, grid_lon, nb);
+    EFA_HIP(hipMemcpyAsync(c->glat.p, pin, nb, hipMemcpyHostToDevice, c->stream));
+    EFA_HIP(hipMemcpyAsync(c->glon.p, pin + nb, nb, hipMemcpyHostToDevice, c->stream));
+    c->grid_ncol = ncol;
+  }
+  c->grid_ready = true;
+  return EFA_OK;
+}
+
+int read_gc_pairs(efa_ctx* c) {
+  if (!c->gc_pairs_pending) return EFA_OK;
+  c->gc_pairs_pending = false;
+  unsigned long long h_pairs = 0;
+  EFA_HIP(hipMemcpyAsync(&h_pairs, c->gc_pairs.p, sizeof(h_pairs), hipMemcpyDeviceToHost, c->stream));
+  EFA_HIP(hipStreamSynchronize(c->stream));
+  c->gc_active_pairs = (long)h_pairs;
   return EFA_OK;
 }
 
@@ -735,6 +785,7 @@ int state_gc_onepass(efa_ctx* c, long rows, const double* xm_in, const double* X
   EFA_TRY(c->gc_obtrig.reserve((size_t)P * 6 * sizeof(double)));
   EFA_TRY(c->gc_off.reserve((size_t)(nblk + 1) * sizeof(long)));
   EFA_TRY(c->gc_pairs.reserve(sizeof(unsigned long long)));
+  EFA_TRY(read_gc_pairs(c));  // (the previous sweep's count, before the counter is cleared: that sweep is long done)
   EFA_HIP(hipMemsetAsync(c->gc_pairs.p, 0, sizeof(unsigned long long), s));
   EFA_HIP(launch_gc_bound(ncol, P, c->glat.as<double>(), c->ob_lat.as<double>(), c->ob_hw.as<double>(),
                           c->coef.as<double>(), c->gc_ub.as<int>(), c->gc_off.as<long>(), s));
@@ -766,10 +817,7 @@ int state_gc_onepass(efa_ctx* c, long rows, const double* xm_in, const double* X
   g.xout = xm_out;
   g.fused_members = fused_members;
   EFA_HIP(launch_sweep_gc(g, s));
-  unsigned long long h_pairs = 0;
-  EFA_HIP(hipMemcpyAsync(&h_pairs, c->gc_pairs.p, sizeof(h_pairs), hipMemcpyDeviceToHost, s));
-  EFA_HIP(hipStreamSynchronize(s));
-  c->gc_active_pairs = (long)h_pairs;
+  c->gc_pairs_pending = true;  // read by read_gc_pairs when somebody asks (option "gc_active_pairs") or before the next sweep
   c->state_launches++;
   (void)rows;
   return EFA_OK;
@@ -970,6 +1018,7 @@ int efa_ctx_destroy(efa_ctx* c) {
   c->pin_in.release();
   c->pin_out.release();
   c->pin_fs.release();
+  c->pin_grid.release();
   if (c->ev_fs) (void)hipEventDestroy(c->ev_fs);
   DevBuf* bufs[] = {&c->ob_pack, &c->out_pack, &c->Ye_rec, &c->coef, &c->ob_val, &c->ob_err, &c->ob_asm, &c->ob_lat, &c->ob_lon, &c->ob_hw, &c->ob_errsq,
                     &c->d_prior_mean, &c->d_prior_var, &c->d_post_mean, &c->d_post_var, &c->d_assimilated,
@@ -1050,7 +1099,10 @@ int efa_ctx_get_option(efa_ctx* c, const char* key, long* value) {
   else if (!strcmp(key, "gram")) *value = c->use_gram;
   else if (!strcmp(key, "pipeline")) *value = c->use_pipeline;
   else if (!strcmp(key, "gc_onepass")) *value = c->gc_onepass;
-  else if (!strcmp(key, "gc_active_pairs")) *value = c->gc_active_pairs;
+  else if (!strcmp(key, "gc_active_pairs")) {
+    EFA_TRY(read_gc_pairs(c));
+    *value = c->gc_active_pairs;
+  }
   else if (!strcmp(key, "spin_limit")) *value = c->spin_limit;
   else if (!strcmp(key, "spin_ms")) *value = c->spin_ms;
   else if (!strcmp(key, "cu_count")) *value = c->cu_count;
@@ -1322,12 +1374,22 @@ int efa_ensrf_cycle_dev(efa_ctx* c, long rows, int M, long P, const double* X_de
   c->spec.X = X_dev;
   c->spec.post = post_dev;
   c->spec.rows = (disjoint && loc_mode == EFA_LOC_NONE) ? rows : 0;  // 0: armed only for the optional obs-block copy
+  {
+    const int rg = prepare_grid_early(c, loc_mode, grid_lat, grid_lon, ncol, n_lead, rows);
+    if (rg != EFA_OK) {
+      c->spec = efa_ctx::Spec{};
+      return rg;
+    }
+  }
   const int rc = obs_phase(c, M, P, ym_dev, Yp_dev, ob_value, ob_error, ob_assim, loc_mode, ob_lat, ob_lon, ob_halfwidth_km,
                            prior_mean, prior_var, post_mean, post_var, assimilated);
   const bool launched = c->spec.launched;
   const int pair = c->spec.pair;
   c->spec = efa_ctx::Spec{};
-  if (rc != EFA_OK) return rc;
+  if (rc != EFA_OK) {
+    c->grid_ready = false;
+    return rc;
+  }
   if (launched) {  // Phase B is in the stream already, behind the launch that turned out fine
     c->state_ms = 0.0;
     c->state_launches = 1;
