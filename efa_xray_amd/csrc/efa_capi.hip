@@ -1109,7 +1109,6 @@ int efa_ctx_get_option(efa_ctx* c, const char* key, long* value) {
   else if (!strcmp(key, "phase_a_kind")) *value = c->phase_a_kind;
   else if (!strcmp(key, "pipe_dbg_addr")) *value = (long)reinterpret_cast<uintptr_t>(c->dbg.p);
   else if (!strcmp(key, "traj_addr")) *value = (long)reinterpret_cast<uintptr_t>(c->traj.p);  // (diagnostic tools only)
-  else if (!strcmp(key, "traj_addr")) *value = (long)reinterpret_cast<uintptr_t>(c->traj.p);  // diagnostic
   else if (!strcmp(key, "device")) *value = c->device;
   else return fail(EFA_ERR_INVALID, "unknown option '%s'", key);
   return EFA_OK;
