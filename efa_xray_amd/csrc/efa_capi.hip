@@ -157,6 +157,20 @@ struct efa_ctx {
   DevBuf W;           // taper table [nb][ncol]
   DevBuf gc_cnt, gc_ub, gc_order, gc_obtrig, gc_off, gc_idx, gc_wts, gc_pairs;  // one-pass GC sweep: CSR active lists
   long gc_active_pairs = 0;  // (column, ob) pairs with a non-zero taper in the last one-pass sweep
+  // What depends on the GEOMETRY of a localised cycle only -- the obs' positions, radii and assimilate flags, the column grid --
+  // is kept from one cycle to the next while that geometry is unchanged (a fixed observing network on a fixed grid): the obs-obs
+  // taper table of Phase A and the per-block active lists of the one-pass sweep (indices, tapers, hand-out order; the gains are
+  // folded in by the sweep itself, cycle by cycle).  Compared by content on the host, never by pointer.
+  std::vector<double> geo_lat, geo_lon, geo_hw;
+  std::vector<uint8_t> geo_assim;
+  long geo_serial = 0;       // bumped whenever the obs geometry of a call differs from the previous call's
+  long grid_serial = 0;      // bumped whenever the device copy of the column grid is rewritten
+  long tw_serial = -1, tw_Pw = -1, tw_Rw = -1;  // what the obs-obs taper table on the device was built from
+  const void* tw_ptr = nullptr;
+  bool gc_list_valid = false;
+  long gc_list_geo = -1, gc_list_grid = -1, gc_list_ncol = -1, gc_list_P = -1;
+  const void* gc_list_ptrs[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
+  long geometry_reuse = 1;   // option "geometry_reuse" (0: rebuild every cycle)
   bool gc_pairs_pending = false;  // ... still on the device (read when asked for, or before the counter is cleared again: a read
                                   // behind the sweep would hold the host until the sweep is done, cycle after cycle)
   PinBuf pin_grid;           // pinned mirror of the column lat/lon on the device (glat | glon)
@@ -313,6 +327,19 @@ int obs_phase(efa_ctx* c, int M, long P, double* ym_dev, double* Yp_dev, const d
   }
   c->h_assim.assign(ob_assim, ob_assim + P);
   for (long k = 0; k < P; ++k) c->n_active += ob_assim[k] ? 1 : 0;
+  if (loc_mode == EFA_LOC_GC) {
+    const size_t nb8 = (size_t)P * sizeof(double);
+    const bool same = (long)c->geo_lat.size() == P && std::memcmp(c->geo_lat.data(), ob_lat, nb8) == 0 &&
+                      std::memcmp(c->geo_lon.data(), ob_lon, nb8) == 0 && std::memcmp(c->geo_hw.data(), ob_hw, nb8) == 0 &&
+                      std::memcmp(c->geo_assim.data(), ob_assim, (size_t)P) == 0;
+    if (!same) {
+      c->geo_lat.assign(ob_lat, ob_lat + P);
+      c->geo_lon.assign(ob_lon, ob_lon + P);
+      c->geo_hw.assign(ob_hw, ob_hw + P);     // (sanitised above)
+      c->geo_assim.assign(ob_assim, ob_assim + P);
+      c->geo_serial++;
+    }
+  }
 
   const bool carry_T = (loc_mode == EFA_LOC_NONE) && transform_supported(M) && (c->path != EFA_PATH_SWEEP);
   const long extra = carry_T ? M : 0;
@@ -511,8 +538,16 @@ int obs_phase(efa_ctx* c, int M, long P, double* ym_dev, double* Yp_dev, const d
       if (loc_mode == EFA_LOC_GC) {
         EFA_TRY(c->tw_mat.reserve((size_t)Pw * Rw * sizeof(double)));
         EFA_TRY(c->gc_obtrig.reserve((size_t)Pw * 6 * sizeof(double)));
-        EFA_HIP(launch_obs_taper_matrix(Pw, Rw, c->ob_lat.as<double>() + w0, c->ob_lon.as<double>() + w0, c->ob_hw.as<double>() + w0,
-                                        c->gc_obtrig.as<double>(), c->tw_mat.as<double>(), s));
+        const bool tw_ok = c->geometry_reuse && direct && c->tw_serial == c->geo_serial && c->tw_Pw == Pw && c->tw_Rw == Rw &&
+                           c->tw_ptr == c->tw_mat.p;
+        if (!tw_ok) {
+          EFA_HIP(launch_obs_taper_matrix(Pw, Rw, c->ob_lat.as<double>() + w0, c->ob_lon.as<double>() + w0, c->ob_hw.as<double>() + w0,
+                                          c->gc_obtrig.as<double>(), c->tw_mat.as<double>(), s));
+          c->tw_serial = direct ? c->geo_serial : -1;  // (a window's table is not the whole block's)
+          c->tw_Pw = Pw;
+          c->tw_Rw = Rw;
+          c->tw_ptr = c->tw_mat.p;
+        }
         pa.tw = c->tw_mat.as<double>();
       }
       pa.coef = c->coef.as<double>() + (size_t)w0 * kCoefStride;
@@ -728,6 +763,7 @@ int prepare_grid(efa_ctx* c, const double* grid_lat, const double* grid_lon, lon
   EFA_TRY(h2d(c, c->glat, grid_lat, (size_t)ncol * sizeof(double)));
   EFA_TRY(h2d(c, c->glon, grid_lon, (size_t)ncol * sizeof(double)));
   c->grid_ncol = -1;
+  c->grid_serial++;
   EFA_HIP(hipStreamSynchronize(c->stream));  // caller may reuse grid_lat/grid_lon on return
   return EFA_OK;
 }
@@ -757,6 +793,7 @@ int prepare_grid_early(efa_ctx* c, int loc_mode, const double* grid_lat, const d
     EFA_HIP(hipMemcpyAsync(c->glat.p, pin, nb, hipMemcpyHostToDevice, c->stream));
     EFA_HIP(hipMemcpyAsync(c->glon.p, pin + nb, nb, hipMemcpyHostToDevice, c->stream));
     c->grid_ncol = ncol;
+    c->grid_serial++;
   }
   c->grid_ready = true;
   return EFA_OK;
@@ -785,6 +822,11 @@ int state_gc_onepass(efa_ctx* c, long rows, const double* xm_in, const double* X
   EFA_TRY(c->gc_obtrig.reserve((size_t)P * 6 * sizeof(double)));
   EFA_TRY(c->gc_off.reserve((size_t)(nblk + 1) * sizeof(long)));
   EFA_TRY(c->gc_pairs.reserve(sizeof(unsigned long long)));
+  const void* ptrs[5] = {c->gc_off.p, c->gc_cnt.p, c->gc_order.p, c->gc_idx.p, c->gc_wts.p};
+  const bool lists_ok = c->geometry_reuse && c->gc_list_valid && c->gc_list_geo == c->geo_serial && c->gc_list_grid == c->grid_serial &&
+                        c->gc_list_ncol == ncol && c->gc_list_P == P && std::memcmp(ptrs, c->gc_list_ptrs, sizeof(ptrs)) == 0;
+  if (!lists_ok) {
+  c->gc_list_valid = false;
   EFA_TRY(read_gc_pairs(c));  // (the previous sweep's count, before the counter is cleared: that sweep is long done)
   EFA_HIP(hipMemsetAsync(c->gc_pairs.p, 0, sizeof(unsigned long long), s));
   EFA_HIP(launch_gc_bound(ncol, P, c->glat.as<double>(), c->ob_lat.as<double>(), c->ob_hw.as<double>(),
@@ -798,6 +840,18 @@ int state_gc_onepass(efa_ctx* c, long rows, const double* xm_in, const double* X
                          c->ob_lon.as<double>(), c->ob_hw.as<double>(), c->coef.as<double>(), c->gc_obtrig.as<double>(),
                          c->gc_off.as<long>(), c->gc_cnt.as<int>(), c->gc_idx.as<int>(), c->gc_wts.as<double>(), c->gc_order.as<int>(),
                          c->gc_pairs.as<unsigned long long>(), s));
+  c->gc_list_valid = true;
+  c->gc_list_geo = c->geo_serial;
+  c->gc_list_grid = c->grid_serial;
+  c->gc_list_ncol = ncol;
+  c->gc_list_P = P;
+  c->gc_list_ptrs[0] = c->gc_off.p;
+  c->gc_list_ptrs[1] = c->gc_cnt.p;
+  c->gc_list_ptrs[2] = c->gc_order.p;
+  c->gc_list_ptrs[3] = c->gc_idx.p;
+  c->gc_list_ptrs[4] = c->gc_wts.p;
+  c->gc_pairs_pending = true;  // read by read_gc_pairs when somebody asks (option "gc_active_pairs") or before the next build
+  }
   GcSweepArgs g{};
   g.ncol = ncol;
   g.n_lead = n_lead;
@@ -817,7 +871,6 @@ int state_gc_onepass(efa_ctx* c, long rows, const double* xm_in, const double* X
   g.xout = xm_out;
   g.fused_members = fused_members;
   EFA_HIP(launch_sweep_gc(g, s));
-  c->gc_pairs_pending = true;  // read by read_gc_pairs when somebody asks (option "gc_active_pairs") or before the next sweep
   c->state_launches++;
   (void)rows;
   return EFA_OK;
@@ -1066,6 +1119,8 @@ int efa_ctx_set_option(efa_ctx* c, const char* key, long value) {
     c->use_pipeline = value ? 1 : 0;
   } else if (!strcmp(key, "gc_onepass")) {
     c->gc_onepass = value ? 1 : 0;
+  } else if (!strcmp(key, "geometry_reuse")) {
+    c->geometry_reuse = value ? 1 : 0;
   } else if (!strcmp(key, "own_stream")) {
     c->stream = c->own_stream;  // back to the context's private non-blocking stream
   } else if (!strcmp(key, "pipe_debug")) {
@@ -1099,6 +1154,7 @@ int efa_ctx_get_option(efa_ctx* c, const char* key, long* value) {
   else if (!strcmp(key, "gram")) *value = c->use_gram;
   else if (!strcmp(key, "pipeline")) *value = c->use_pipeline;
   else if (!strcmp(key, "gc_onepass")) *value = c->gc_onepass;
+  else if (!strcmp(key, "geometry_reuse")) *value = c->geometry_reuse;
   else if (!strcmp(key, "gc_active_pairs")) {
     EFA_TRY(read_gc_pairs(c));
     *value = c->gc_active_pairs;

@@ -1192,3 +1192,62 @@ def test_fused_cycle_in_place_and_edge_cases():
         assert_parity(post.download(), ref_post, "post after four cycles")
     finally:
         ctx.set_option("timing", 0)
+
+
+@pytest.mark.gpu
+def test_geometry_reuse_across_localised_cycles():
+    """The obs-obs taper table and the sweep's active lists depend on the geometry only and are kept from cycle to cycle
+    (efa_ensrf_cycle_dev, option geometry_reuse): a second cycle with new obs values / error variances / state on the same
+    geometry must use them and still match the oracle; a moved ob, a changed assimilate flag, a changed radius and a changed grid
+    must each be noticed."""
+    ctx = _ctx()
+    base = _random_case(808, 4 * 600, 40, 150, True, frac_assim=0.9, ncol=600)
+    N, M, P = base["N"], base["M"], base["P"]
+    rng = np.random.default_rng(809)
+
+    def run(c, reuse=1):
+        ctx.set_option("geometry_reuse", reuse)
+        X = ctx.to_device(c["X"])
+        post = ctx.empty((N, M))
+        Yp = ctx.to_device(c["HX"])
+        ym = ctx.empty((P,))
+        ctx.form_perts(P, M, Yp, ym, Yp)
+        d = ctx.ensrf_cycle(N, M, P, X, post, ym, Yp, c["val"], c["err"], c["asm"], 1, c["ob_lat"], c["ob_lon"], c["hw"],
+                            c["lat"].reshape(-1), c["lon"].reshape(-1), c["n_lead"])
+        xam, Xap, diag = _run_oracle(c)
+        assert_parity(post.download(), orc.format_posterior_state(xam, Xap, N), "post")
+        assert_parity(d["post_var"], diag["post_var"], "post_var")
+        return post.download(), int(ctx.get_option("gc_active_pairs"))
+
+    def variant(**changes):
+        c = dict(base)
+        for k in ("X", "HX", "val", "err", "asm", "ob_lat", "ob_lon", "hw", "lat", "lon"):
+            c[k] = np.array(base[k], copy=True)
+        c.update(changes)
+        return c
+
+    try:
+        p0, n0 = run(base)
+        # same geometry, everything else new
+        c1 = variant(X=base["X"] + rng.standard_normal(base["X"].shape), err=rng.uniform(0.3, 3.0, P))
+        c1["HX"] = c1["X"][rng.choice(N, P, replace=False)]
+        c1["val"] = c1["HX"].mean(axis=1) + rng.standard_normal(P)
+        p1, n1 = run(c1)
+        assert n1 == n0
+        p1b, _ = run(c1, reuse=0)              # rebuilt from scratch: the same bits
+        assert np.array_equal(p1, p1b)
+        # one ob moved / one flag flipped / one radius changed / the grid shifted: each must be rebuilt for
+        lat2 = base["ob_lat"].copy()
+        lat2[7] += 3.0
+        run(variant(ob_lat=lat2))
+        asm2 = base["asm"].copy()
+        asm2[11] = not asm2[11]
+        run(variant(asm=asm2))
+        hw2 = base["hw"].copy()
+        hw2[np.flatnonzero(base["asm"])[3]] *= 0.37
+        _, n4 = run(variant(hw=hw2))
+        assert n4 != n0
+        run(variant(lat=base["lat"] + 0.5))
+        run(base)
+    finally:
+        ctx.set_option("geometry_reuse", 1)
