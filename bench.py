@@ -236,11 +236,19 @@ def measure(args, wl, strong, world, rank, eng, dist, torch, seed, balance=True)
     # deferred -- no call waits for its own events, the sums are read ONCE after the closing synchronisation; with "timing" 1
     # every state phase ended in an event wait, so the host could not prepare the next cycle while the transform ran)
     ctx.last_timing()                      # (clears the sums of the warm-up steps)
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        d = sh.update(X, post, idx, wts, ob, glat, glon)
-    sync_all()
-    elapsed = time.perf_counter() - t0
+    # the interpreter's cyclic garbage collector stays out of the timed region, as in timeit: a full collection with torch
+    # imported takes ~30 ms, four cycles' worth, and falls into one run in a few (tools/cycle_jitter.py: 1 of 400 cycles)
+    import gc
+    gc.collect()
+    gc.disable()
+    try:
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            d = sh.update(X, post, idx, wts, ob, glat, glon)
+        sync_all()
+        elapsed = time.perf_counter() - t0
+    finally:
+        gc.enable()
     t = ctx.last_timing()
     state_ms, obs_ms, launches, path_taken = t["state_ms"], t["obs_ms"], t["state_launches"], t["path"]
     my_elapsed = elapsed
