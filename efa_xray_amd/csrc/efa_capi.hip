@@ -191,7 +191,8 @@ struct efa_ctx {
   // --- timing -----------------------------------------------------------------
   hipEvent_t ev[7] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};  // obs phase 0..1; state phase 2..3 and (the fused cycle's second pair) 4..5; 6: Phase A's results on the host (fused cycle)
   double state_ms = 0.0, obs_ms = 0.0;
-  bool obs_ms_pending = false;  // ev[0] .. ev[1] of the last obs phase not read yet
+  bool obs_ms_pending = false;  // ev[0] .. ev[obs_end_ev] of the last obs phase not read yet
+  int obs_end_ev = 1;           // 1, or the start event of the state pair a speculative transform was put behind
   bool state_ms_pending = false;  // ev[2] .. ev[3] of the last state phase not read yet
   bool state_ms_pending2 = false; // ev[4] .. ev[5] likewise (efa_ensrf_cycle_dev alternates the pairs: it records a state phase's
                                   // events BEFORE the stream is synchronised, while the previous cycle's may still be unread)
@@ -220,7 +221,7 @@ using namespace efa;
 void harvest_obs_ms(efa_ctx* c) {
   if (!c->obs_ms_pending) return;
   float ms = 0.f;
-  if (hipEventSynchronize(c->ev[1]) == hipSuccess && hipEventElapsedTime(&ms, c->ev[0], c->ev[1]) == hipSuccess) {
+  if (hipEventSynchronize(c->ev[c->obs_end_ev]) == hipSuccess && hipEventElapsedTime(&ms, c->ev[0], c->ev[c->obs_end_ev]) == hipSuccess) {
     c->obs_ms = ms;
     c->obs_ms_sum += ms;
   } else {
@@ -603,12 +604,11 @@ int obs_phase(efa_ctx* c, int M, long P, double* ym_dev, double* Yp_dev, const d
         if (c->spec.armed && c->spec.rows > 0 && direct && carry_T && c->n_active > 0 &&
             (c->path == EFA_PATH_TRANSFORM || (c->path == EFA_PATH_AUTO && c->n_active > M / 2))) {
           const int pr = c->state_ms_pending ? 1 : 0;
-          EFA_HIP(hipEventRecord(c->ev[6], s));  // the status words and diagnostics are on the host: what the host waits for below
-          if (c->timing) {
-            harvest_state_pair(c, pr);  // (both pairs unread cannot happen across the synchronisation below; kept correct anyway)
-            EFA_HIP(hipEventRecord(c->ev[1], s));
-            EFA_HIP(hipEventRecord(c->ev[2 + 2 * pr], s));
-          }
+          if (c->timing) harvest_state_pair(c, pr);  // (both pairs unread cannot happen across the wait below; kept correct anyway)
+          // ONE event between Phase A and the transform (each record idles the stream ~6 us): the status words and diagnostics are on
+          // the host -- what the host waits for below --, the obs interval ends and the state interval of this pair begins
+          EFA_HIP(hipEventRecord(c->ev[2 + 2 * pr], s));
+          c->obs_end_ev = 2 + 2 * pr;
           TransformArgs t{};
           t.Xin = c->spec.X;
           t.Xout = c->spec.post;
@@ -622,7 +622,7 @@ int obs_phase(efa_ctx* c, int M, long P, double* ym_dev, double* Yp_dev, const d
           c->spec.pair = pr;
           spec_now = true;
         }
-        if (spec_now) EFA_HIP(hipEventSynchronize(c->ev[6]));  // (not the stream: the transform behind it is to run while the host goes on)
+        if (spec_now) EFA_HIP(hipEventSynchronize(c->ev[2 + 2 * c->spec.pair]));  // (not the stream: the transform behind it is to run while the host goes on)
         else EFA_HIP(hipStreamSynchronize(s));
         c->spec.launched = false;
         if (spec_now && c->timing) harvest_state_pair(c, 1 - c->spec.pair);  // the previous cycle's interval: complete by now
@@ -716,7 +716,10 @@ int obs_phase(efa_ctx* c, int M, long P, double* ym_dev, double* Yp_dev, const d
     EFA_HIP(hipMemcpyAsync(Yp_dev, Yw, (size_t)P * M * sizeof(double), hipMemcpyDeviceToDevice, s));
     EFA_HIP(hipMemcpyAsync(ym_dev, ymw, dP, hipMemcpyDeviceToDevice, s));
   }
-  if (c->timing && !c->spec.launched) EFA_HIP(hipEventRecord(c->ev[1], s));  // (a speculative transform: recorded in front of it)
+  if (c->timing && !c->spec.launched) {  // (behind a speculative transform the interval ended at the event in front of it)
+    EFA_HIP(hipEventRecord(c->ev[1], s));
+    c->obs_end_ev = 1;
+  }
 
   // diagnostics back to the caller (ensrf.py:66,70,75,146-149)
   if (!diag_on_host) {
