@@ -287,6 +287,8 @@ int check_common(int M, long P) {
   return EFA_OK;
 }
 
+bool auto_transform(int M, long n_active, bool member_form);  // (with Phase B's path choice, below)
+
 // ---- Phase A ---------------------------------------------------------------
 int obs_phase(efa_ctx* c, int M, long P, double* ym_dev, double* Yp_dev, const double* ob_value,
               const double* ob_error, const uint8_t* ob_assim, int loc_mode, const double* ob_lat,
@@ -602,7 +604,7 @@ int obs_phase(efa_ctx* c, int M, long P, double* ym_dev, double* Yp_dev, const d
         // a result.  The device then runs Phase A -> Phase B with no host round trip in between.
         bool spec_now = false;
         if (c->spec.armed && c->spec.rows > 0 && direct && carry_T && c->n_active > 0 &&
-            (c->path == EFA_PATH_TRANSFORM || (c->path == EFA_PATH_AUTO && c->n_active > M / 2))) {
+            (c->path == EFA_PATH_TRANSFORM || (c->path == EFA_PATH_AUTO && auto_transform(M, c->n_active, true)))) {
           const int pr = c->state_ms_pending ? 1 : 0;
           if (c->timing) harvest_state_pair(c, pr);  // (both pairs unread cannot happen across the wait below; kept correct anyway)
           // ONE event between Phase A and the transform (each record idles the stream ~6 us): the status words and diagnostics are on
@@ -747,11 +749,23 @@ int obs_phase(efa_ctx* c, int M, long P, double* ym_dev, double* Yp_dev, const d
   return EFA_OK;
 }
 
-bool want_transform(const efa_ctx* c) {
+// path "auto": one transform pass or sweep passes?  By FLOPS one transform pass is M/2 observations of sweep arithmetic (the rule of
+// rounds 1-2), but the transform runs on the matrix cores at 49 TFLOP/s and the sweep on the vector ALUs at 10-20, and in MEMBER form
+// (prior members in, posterior members out) the sweep path is three passes over the state -- form the perturbations, sweep, rebuild
+// the members -- where the transform is one.  Measured at 1e7 x 100 (profiles/r03_auto_path.txt): member form 8 obs 10.6 ms by
+// sweeps, 4.1 by the transform (48 obs: 16.9 vs 4.1); perturbation form 8 / 16 obs per sweep launch 3.4 / 4.5 ms vs 4.5.
+// Above 136 members the transform re-reads the state once per group of 64 output columns: the flops rule stays.
+bool auto_transform(int M, long n_active, bool member_form) {
+  if (n_active <= 0) return false;
+  if (M > 136) return n_active > M / 2;
+  if (member_form) return true;
+  return n_active > M / 8;
+}
+bool want_transform(const efa_ctx* c, bool member_form) {
   if (!c->have_transform) return false;
   if (c->path == EFA_PATH_TRANSFORM) return true;
   if (c->path == EFA_PATH_SWEEP) return false;
-  return c->n_active > c->M / 2;  // one pass costs about M/2 observations of sweep arithmetic
+  return auto_transform(c->M, c->n_active, member_form);
 }
 
 int prepare_grid(efa_ctx* c, const double* grid_lat, const double* grid_lon, long ncol, long n_lead, long rows) {
@@ -942,7 +956,7 @@ int state_phase(efa_ctx* c, long rows, int M, const double* xm_in, const double*
   EFA_TRY(prepare_grid(c, grid_lat, grid_lon, ncol, n_lead, rows));
   hipStream_t s = c->stream;
   if (c->timing) EFA_HIP(hipEventRecord(c->ev[2], s));
-  if (c->P > 0 && c->n_active > 0 && want_transform(c)) {
+  if (c->P > 0 && c->n_active > 0 && want_transform(c, false)) {
     TransformArgs t{};
     t.Xin = Xp_in;
     t.xin = xm_in;
@@ -1373,7 +1387,7 @@ int efa_state_cycle_dev(efa_ctx* c, long rows, int M, const double* X_dev, doubl
   EFA_TRY(prepare_grid(c, grid_lat, grid_lon, ncol, n_lead, rows));
   hipStream_t s = c->stream;
   if (c->timing) EFA_HIP(hipEventRecord(c->ev[2], s));
-  if (c->P > 0 && c->n_active > 0 && want_transform(c)) {
+  if (c->P > 0 && c->n_active > 0 && want_transform(c, true)) {
     efa::TransformArgs t{};
     t.Xin = X_dev;
     t.Xout = post_dev;
