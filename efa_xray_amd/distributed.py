@@ -43,9 +43,11 @@ def column_bounds(ncol, world_size):
 
 
 GC_BLOCK = 16          # columns per block of the one-pass localised sweep (efa_gcsweep.hip)
-# A block's read + write of its rows, in (column, ob) pairs.  Calibrated on configs[3] on one MI355X: the sweep spends
-# 0.41 us of one CU per pair (148 slabs x 100 members) and a block's 3.8 MB take 0.22 ms of one CU's share of HBM.
-GC_FIXED_COST = 512.0
+# A block's read + write of its rows (and its staging), in (column, ob) pairs.  Calibrated on configs[3] on one MI355X by the measured
+# per-shard state phases of the 8-way split (tools/shard_balance.py): 512 (round 3's first estimate: 0.41 us of one CU per pair, 0.22 ms of
+# one CU's HBM share per block) left the equatorial shards -- many blocks, short lists -- 4 % slower than the polar ones with the
+# row-per-lane sweep (16.68 vs 15.95 ms); 900 tips it the other way; at 760 the eight shards take 16.03-16.33 ms (max / mean 1.011).
+GC_FIXED_COST = 760.0
 
 
 def balanced_column_bounds(block_pairs, ncol, world_size, block=GC_BLOCK, fixed=GC_FIXED_COST):
