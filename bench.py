@@ -61,8 +61,8 @@ WORKLOADS = {
 def parse_args():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=5)
-    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--workload", default=None, choices=sorted(WORKLOADS),
                     help="default: headline at --gpus 1, cfg4 (configs[3], one global state) at --gpus > 1")
     ap.add_argument("--scaling", default=None, choices=["weak", "strong"], help="default: strong (the same thing at N = 1)")
